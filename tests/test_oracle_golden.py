@@ -140,7 +140,7 @@ def _check_iteration(golden, prefix, out, g_sd, d_sd, rel=2e-4, check_grads=True
         for k, p in sd.items():
             # first AdamW steps move every element by ~lr*sign(g): a sign flip of a near-zero gradient
             # shifts one element by 2*lr, hence the absolute element bound of 3*lr*n_steps.
-            assert_summary_close(p, golden[f"{prefix}/{kind}_params/{k}"], RTOL, f"{prefix} {kind}_param {k}",
+            assert_summary_close(p, golden[f"{prefix}/{kind}_params/{k}"], RTOL if rel <= 2e-4 else 1e-3, f"{prefix} {kind}_param {k}",
                                  elem_atol=2.5e-3, sum_atol=2e-3)
 
 
