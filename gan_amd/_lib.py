@@ -1,0 +1,131 @@
+"""ctypes binding of libgan_amd.so (the C ABI in include/gan_amd.h).
+
+There is no CPU or PyTorch fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libgan_amd.so"
+
+GA_MAX_PHASE = 8
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_ELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3, 4
+DACT_NONE, DACT_LRELU_FROM_OUT, DACT_ELU_FROM_IN = 0, 1, 2
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+PACK_CONV_FWD, PACK_CONV_DGRAD_S1, PACK_CONV_DGRAD_STRIDED, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3, 4
+RED_ABSDIFF, RED_RELU1M, RED_RELU1P, RED_SUM, RED_SQ = 0, 1, 2, 3, 4
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+        ("dact_src", C.c_void_p),
+        ("B", C.c_int), ("Lin", C.c_int), ("Cin", C.c_int), ("M", C.c_int),
+        ("Lout", C.c_int), ("LoutTot", C.c_int),
+        ("J", C.c_int), ("in_stride", C.c_int), ("tap_step", C.c_int), ("off0", C.c_int),
+        ("out_stride", C.c_int), ("t0", C.c_int),
+        ("pad_mode", C.c_int), ("pre_act", C.c_int), ("post_act", C.c_int), ("dact_mode", C.c_int),
+        ("accumulate", C.c_int), ("nphase", C.c_int),
+        ("phase_off0", C.c_int * GA_MAX_PHASE),
+    ]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [
+        ("g", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p),
+        ("B", C.c_int), ("Lin", C.c_int), ("Cin", C.c_int), ("M", C.c_int), ("Lout", C.c_int), ("J", C.c_int),
+        ("in_stride", C.c_int), ("tap_step", C.c_int), ("off0", C.c_int),
+        ("LgTot", C.c_int), ("g_stride", C.c_int), ("g_phase", C.c_int), ("rows_per_split", C.c_int),
+    ]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SIGNATURES = {
+    "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
+    "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
+    "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
+    "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_unpack_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_wn_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+    "ga_gn_stats": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ga_gn_film_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ga_gn_film_act_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ga_tanh_residual_fwd": [_P, _P, _P, _I, _Z, _F, _P],
+    "ga_tanh_residual_bwd": [_P, _P, _P, _I, _Z, _F, _P],
+    "ga_avgpool1d_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ga_avgpool1d_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ga_act_bwd": [_P, _P, _P, _I, _Z, _I, _P],
+    "ga_colsum": [_P, _I, _Z, _I, _P, _P],
+    "ga_reduce": [_P, _P, _I, _Z, _I, _F, _P, _P],
+    "ga_reduce_grad": [_P, _P, _I, _Z, _I, _P, _F, _P, _I, _P],
+    "ga_latent_loss_fwd": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "ga_latent_loss_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "ga_stft_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_stft_loss_fwd": [_P, _P, _I, _Z, _I, _I, _P, _P],
+    "ga_stft_loss_bwd": [_P, _P, _I, _Z, _I, _I, _P, _P, _P],
+    "ga_stft_unpad_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_grad_sqnorm": [_P, _Z, _P, _P],
+    "ga_adamw_fused": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _P],
+}
+EXPORTED = sorted(list(_SIGNATURES) + ["ga_packed_elems", "ga_build_target"])
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was not built)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m gan_amd.build` (hipcc, gfx950). "
+                "gan_amd has no CPU/PyTorch fallback for its kernels."
+            )
+        l = C.CDLL(str(LIB_PATH))
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        l.ga_packed_elems.argtypes = [_I, _I, _I, _I, _I]
+        l.ga_packed_elems.restype = C.c_size_t
+        l.ga_build_target.argtypes = []
+        l.ga_build_target.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+_ERR = {1: "GA_ERR_ARG (bad shape / unsupported configuration)", 2: "GA_ERR_LAUNCH (HIP launch failed)",
+        3: "GA_ERR_ALIGN (pointer alignment)"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"gan_amd: {what} failed with status {rc}: {_ERR.get(rc, '?')}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"gan_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gan_amd ops run on the GPU only (HIP kernels); got a CPU tensor. "
+                               "There is no CPU fallback - use oracle/ for CPU checks.")

@@ -1,0 +1,660 @@
+// HBM-bound kernels of the lab3 codec GAN step: weight-norm + weight packing, GroupNorm+FiLM+SiLU,
+// tanh residual, avg-pool, activation backward, column sums, loss reductions, latent losses,
+// gradient square-norm and the fused clipped AdamW.  All activations are channels-last [B][L][C].
+#include "common.h"
+
+// ================================================================================================
+// weight-norm scale: scale[r] = g[r] / ||v[r,:]||, norm[r] = ||v[r,:]||   (torch _weight_norm, dim=0)
+__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                        int n, float* __restrict__ scale, float* __restrict__ norm) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float a = v[(size_t)r * n + i];
+        s = fmaf(a, a, s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float nr = sqrtf(s);
+        norm[r] = nr;
+        scale[r] = g[r] / nr;
+    }
+}
+
+// packed position of source weight element (s0, s1, k); see ga_pack_weights in include/gan_amd.h
+
+__device__ __forceinline__ size_t pack_index(int mode, int s0, int s1, int k, int D0, int D1, int K, int S, int P) {
+    switch (mode) {
+        case GA_PACK_CONV_FWD:  // src [Co][Ci][K] -> [Co][K][Ci]
+            return ((size_t)s0 * K + k) * D1 + s1;
+        case GA_PACK_CONV_DGRAD_S1:  // -> [Ci][K][Co], taps flipped
+            return ((size_t)s1 * K + (K - 1 - k)) * D0 + s0;
+        case GA_PACK_CONV_DGRAD_STRIDED: {  // -> [S][Ci][Jmax][Co]
+            const int Jmax = (K + S - 1) / S;
+            const int rho = k % S;
+            int r = (rho - P) % S;
+            if (r < 0) r += S;
+            const int jp = Jmax - 1 - k / S;
+            return (((size_t)r * D1 + s1) * Jmax + jp) * D0 + s0;
+        }
+        case GA_PACK_CONVT_FWD: {  // src [Ci][Co][K=2S] -> [S][Co][2][Ci]
+            const int r = k % S, j = 1 - k / S;
+            return (((size_t)r * D1 + s1) * 2 + j) * D0 + s0;
+        }
+        default:  // GA_PACK_CONVT_DGRAD: src [Ci][Co][K] -> [Ci][K][Co]
+            return ((size_t)s0 * K + k) * D1 + s1;
+    }
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ src, const float* __restrict__ scale, T* __restrict__ dst,
+                                    int mode, int D0, int D1, int K, int S, int P) {
+    const size_t n = (size_t)D0 * D1 * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int s1 = (int)((i / K) % D1);
+        const int s0 = (int)(i / ((size_t)K * D1));
+        float v = src[i];
+        if (scale) v *= scale[s0];
+        dst[pack_index(mode, s0, s1, k, D0, D1, K, S, P)] = (T)v;
+    }
+}
+
+// inverse gather: dw[s0][s1][k] (+)= packed[pack_index]
+__global__ void unpack_grad_kernel(const float* __restrict__ packed, float* __restrict__ dw, int mode, int D0, int D1,
+                                   int K, int S, int P, int accumulate) {
+    const size_t n = (size_t)D0 * D1 * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int s1 = (int)((i / K) % D1);
+        const int s0 = (int)(i / ((size_t)K * D1));
+        const float v = packed[pack_index(mode, s0, s1, k, D0, D1, K, S, P)];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+// weight-norm backward on the effective-weight gradient dw[R][n]:
+//   dg[r] = <dw_r, v_r> / ||v_r||;  dv_r = (g/||v||) * dw_r - (g * <dw_r, v_r> / ||v||^3) * v_r
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                      const float* __restrict__ g, const float* __restrict__ norm, int n,
+                                                      float* __restrict__ dv, float* __restrict__ dg, int accumulate) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s = fmaf(dw[(size_t)r * n + i], v[(size_t)r * n + i], s);
+    s = block_sum(s, red);
+    const float nr = norm[r], gr = g[r];
+    const float a = gr / nr, bcoef = gr * s / (nr * nr * nr);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const size_t idx = (size_t)r * n + i;
+        const float val = a * dw[idx] - bcoef * v[idx];
+        dv[idx] = accumulate ? dv[idx] + val : val;
+    }
+    if (threadIdx.x == 0) dg[r] = accumulate ? dg[r] + s / nr : s / nr;
+}
+
+// ================================================================================================
+// GroupNorm(G) -> FiLM -> SiLU (+ residual), channels-last
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int Tn, int C, int G, float eps,
+                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ float red[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G;
+    const int n = Tn * cg;
+    const T* xb = x + (size_t)b * Tn * C + g * cg;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (float)xb[(size_t)(i / cg) * C + (i % cg)];
+    const float mu = block_sum(s, red) / n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = (float)xb[(size_t)(i / cg) * C + (i % cg)] - mu;
+        q = fmaf(d, d, q);
+    }
+    q = block_sum(q, red) / n;
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = mu;
+        rstd[blockIdx.x] = rsqrtf(q + eps);
+    }
+}
+
+// y = act( ((x-mean)*rstd*gamma+beta) * (1+a[b,c]) + bb[b,c] ) + res ;  ab = [B][2C] (a | b) or null
+template <typename T>
+__global__ void gn_film_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ ab, const T* __restrict__ res, T* __restrict__ y,
+                                       int B, int Tn, int C, int G, int act) {
+    const size_t n = (size_t)B * Tn * C;
+    const int cg = C / G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((size_t)Tn * C));
+        const int sg = b * G + c / cg;
+        float v = ((float)x[i] - mean[sg]) * rstd[sg] * gamma[c] + beta[c];
+        if (ab) v = v * (1.f + ab[(size_t)b * 2 * C + c]) + ab[(size_t)b * 2 * C + C + c];
+        v = act_apply(act, v);
+        if (res) v += (float)res[i];
+        y[i] = (T)v;
+    }
+}
+
+__device__ __forceinline__ float dsilu(float h) {
+    const float s = 1.f / (1.f + __expf(-h));
+    return s * (1.f + h * (1.f - s));
+}
+
+// one block per (b, group).  dgamma/dbeta [C] and dab [B][2C] are accumulated with atomics (caller zeroes).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_film_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ ab, T* __restrict__ dx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dab, int Tn, int C, int G, int act) {
+    __shared__ float red[16];
+    __shared__ float chan[4][256];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G;
+    const int rpi = 256 / cg;  // rows per iteration
+    const int tid = threadIdx.x;
+    const bool active = tid < rpi * cg;
+    const int cl = tid % cg, r0 = tid / cg;
+    const int c = g * cg + cl;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    const float gm = gamma[c], bt = beta[c];
+    const float fa = ab ? ab[(size_t)b * 2 * C + c] : 0.f;
+    const float fb = ab ? ab[(size_t)b * 2 * C + C + c] : 0.f;
+    const size_t base = (size_t)b * Tn * C + c;
+    float s_da = 0.f, s_db = 0.f, s_dg = 0.f, s_dbt = 0.f, s1 = 0.f, s2 = 0.f;
+    if (active) {
+        for (int t = r0; t < Tn; t += rpi) {
+            const size_t idx = base + (size_t)t * C;
+            const float xh = ((float)x[idx] - mu) * rs;
+            const float nv = xh * gm + bt;
+            const float h = nv * (1.f + fa) + fb;
+            float dh = (float)dy[idx];
+            if (act == GA_ACT_SILU) dh *= dsilu(h);
+            s_da = fmaf(dh, nv, s_da);
+            s_db += dh;
+            const float dn = dh * (1.f + fa);
+            s_dg = fmaf(dn, xh, s_dg);
+            s_dbt += dn;
+            const float dxh = dn * gm;
+            s1 += dxh;
+            s2 = fmaf(dxh, xh, s2);
+        }
+    }
+    const float S1 = block_sum(s1, red);
+    const float S2 = block_sum(s2, red);
+    chan[0][tid] = s_da; chan[1][tid] = s_db; chan[2][tid] = s_dg; chan[3][tid] = s_dbt;
+    __syncthreads();
+    if (tid < cg) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = 0; r < rpi; ++r) {
+            a0 += chan[0][r * cg + tid]; a1 += chan[1][r * cg + tid];
+            a2 += chan[2][r * cg + tid]; a3 += chan[3][r * cg + tid];
+        }
+        const int cc = g * cg + tid;
+        if (dab) {
+            atomicAdd(&dab[(size_t)b * 2 * C + cc], a0);
+            atomicAdd(&dab[(size_t)b * 2 * C + C + cc], a1);
+        }
+        atomicAdd(&dgamma[cc], a2);
+        atomicAdd(&dbeta[cc], a3);
+    }
+    const float inv_n = 1.f / (float)(Tn * cg);
+    if (active) {
+        for (int t = r0; t < Tn; t += rpi) {
+            const size_t idx = base + (size_t)t * C;
+            const float xh = ((float)x[idx] - mu) * rs;
+            const float nv = xh * gm + bt;
+            const float h = nv * (1.f + fa) + fb;
+            float dh = (float)dy[idx];
+            if (act == GA_ACT_SILU) dh *= dsilu(h);
+            const float dxh = dh * (1.f + fa) * gm;
+            dx[idx] = (T)(rs * (dxh - S1 * inv_n - xh * S2 * inv_n));
+        }
+    }
+}
+
+// ================================================================================================
+// q_hat = q_src + rscale * tanh(raw)
+template <typename T>
+__global__ void tanh_residual_fwd_kernel(const T* __restrict__ raw, const T* __restrict__ q, T* __restrict__ y, size_t n, float rscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (T)((float)q[i] + rscale * tanhf((float)raw[i]));
+}
+template <typename T>
+__global__ void tanh_residual_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ raw, T* __restrict__ draw, size_t n, float rscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float th = tanhf((float)raw[i]);
+        draw[i] = (T)((float)dy[i] * rscale * (1.f - th * th));
+    }
+}
+
+// AvgPool1d(kernel 4, stride 2, padding 1, count_include_pad) on single-channel rows [B][L] -> [B][Lo]
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int L, int Lo) {
+    const size_t n = (size_t)B * Lo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / Lo), t = (int)(i % Lo);
+        const T* xb = x + (size_t)b * L;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = 2 * t - 1 + k;
+            if (l >= 0 && l < L) s += (float)xb[l];
+        }
+        y[i] = (T)(0.25f * s);
+    }
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int L, int Lo) {
+    const size_t n = (size_t)B * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / L), l = (int)(i % L);
+        // outputs t with 2t-1 <= l <= 2t+2  <=>  (l-2)/2 <= t <= (l+1)/2
+        float s = 0.f;
+        const int tlo = (l - 1) >> 1, thi = (l + 1) >> 1;  // ceil((l-2)/2) == (l-1)>>1 for l>=0 (arith shift handles l=0)
+        for (int t = tlo; t <= thi; ++t)
+            if (t >= 0 && t < Lo) s += (float)dy[(size_t)b * Lo + t];
+        dx[i] = (T)(0.25f * s);
+    }
+}
+
+// ga = gy * act'(.) : mode LRELU_FROM_OUT uses the post-activation output
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ src, T* __restrict__ ga, size_t n, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        ga[i] = (T)((float)gy[i] * dact_apply(mode, (float)src[i]));
+}
+
+// out[m] += sum_rows g[row][m]   (bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, size_t rows, int M, float* __restrict__ out, size_t rows_per_block) {
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    size_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (M <= 128) {
+        // threads: channel = tid % Mp, row lane = tid / Mp
+        __shared__ float part[256];
+        int Mp = 1;
+        while (Mp < M) Mp <<= 1;
+        const int rl = threadIdx.x / Mp, m = threadIdx.x % Mp, nrl = 256 / Mp;
+        float s = 0.f;
+        if (m < M)
+            for (size_t r = r0 + rl; r < r1; r += nrl) s += (float)g[r * M + m];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < Mp && m < M) {
+            float t = 0.f;
+            for (int k = 0; k < nrl; ++k) t += part[k * Mp + m];
+            atomicAdd(&out[m], t);
+        }
+    } else {
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            float s = 0.f;
+            for (size_t r = r0; r < r1; ++r) s += (float)g[r * M + m];
+            atomicAdd(&out[m], s);
+        }
+    }
+}
+
+// ================================================================================================
+// scalar reductions out[0] += scale * sum_i f(a_i, b_i) and their elementwise gradients
+
+__device__ __forceinline__ float red_f(int op, float a, float b) {
+    switch (op) {
+        case GA_RED_ABSDIFF: return fabsf(a - b);
+        case GA_RED_RELU1M: return fmaxf(1.f - a, 0.f);
+        case GA_RED_RELU1P: return fmaxf(1.f + a, 0.f);
+        case GA_RED_SUM: return a;
+        default: return a * a;
+    }
+}
+__device__ __forceinline__ float red_df(int op, float a, float b) {
+    switch (op) {
+        case GA_RED_ABSDIFF: { const float d = a - b; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        case GA_RED_RELU1M: return (1.f - a) > 0.f ? -1.f : 0.f;
+        case GA_RED_RELU1P: return (1.f + a) > 0.f ? 1.f : 0.f;
+        case GA_RED_SUM: return 1.f;
+        default: return 2.f * a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op,
+                                                      float scale, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        s += red_f(op, (float)a[i], b ? (float)b[i] : 0.f);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+
+// ga[i] (+)= coef[0] * scale * d f / d a
+template <typename T>
+__global__ void reduce_grad_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op, const float* __restrict__ coef,
+                                   float scale, T* __restrict__ ga, int accumulate) {
+    const float c = coef[0] * scale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = c * red_df(op, (float)a[i], b ? (float)b[i] : 0.f);
+        if (accumulate) v += (float)ga[i];
+        ga[i] = (T)v;
+    }
+}
+
+// latent losses on [B][T][C]: out[0] = sum |d|, out[1] = sum_t |d[t+1]-d[t]|, out[2+b] = sum_b |d|, d = qh - qs
+template <typename T>
+__global__ __launch_bounds__(256) void latent_loss_fwd_kernel(const T* __restrict__ qh, const T* __restrict__ qs, int Tn, int C,
+                                                               float* __restrict__ out) {
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * Tn * C;
+    const size_t n = (size_t)Tn * C;
+    float s0 = 0.f, s1 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = (float)qh[base + i] - (float)qs[base + i];
+        s0 += fabsf(d);
+        if (i + C < n) {
+            const float d2 = (float)qh[base + i + C] - (float)qs[base + i + C];
+            s1 += fabsf(d2 - d);
+        }
+    }
+    s0 = block_sum(s0, red);
+    s1 = block_sum(s1, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], s0);
+        atomicAdd(&out[1], s1);
+        atomicAdd(&out[2 + b], s0);
+    }
+}
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+template <typename T>
+__global__ void latent_loss_bwd_kernel(const T* __restrict__ qh, const T* __restrict__ qs, int B, int Tn, int C,
+                                       const float* __restrict__ gout /* [2+B] */, T* __restrict__ dqh) {
+    const size_t per = (size_t)Tn * C, n = (size_t)B * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const size_t r = i % per;
+        const float d = (float)qh[i] - (float)qs[i];
+        float g = (gout[0] + gout[2 + b]) * sgn(d);
+        if (r >= (size_t)C) {
+            const float dm = (float)qh[i - C] - (float)qs[i - C];
+            g += gout[1] * sgn(d - dm);
+        }
+        if (r + C < per) {
+            const float dp = (float)qh[i + C] - (float)qs[i + C];
+            g -= gout[1] * sgn(dp - d);
+        }
+        dqh[i] = (T)g;
+    }
+}
+
+// ================================================================================================
+// optimizer: out[0] += sum g^2 ; fused clip + AdamW over flat fp32 buffers
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const size_t n4 = n / 4;
+    const float4* g4 = (const float4*)g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+struct AdamWArgs {
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, grad_scale;
+};
+
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamWArgs& a, float coef) {
+    g *= coef;
+    p *= (1.f - a.lr * a.weight_decay);
+    m = a.beta1 * m + (1.f - a.beta1) * g;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
+    p -= (a.lr / a.bc1) * (m / denom);
+}
+
+// torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm/(norm+1e-6))) folded into torch.optim.AdamW's update.
+// g_out (optional) receives the clipped gradient so p.grad matches the reference after the step.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, size_t n, AdamWArgs a, const float* __restrict__ sqnorm,
+                                                     int write_clipped_grad) {
+    float coef = a.grad_scale;
+    if (a.max_norm > 0.f && sqnorm) {
+        const float total = sqrtf(sqnorm[0]) * a.grad_scale;
+        const float c = a.max_norm / (total + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    const size_t n4 = n / 4;
+    float4* p4 = (float4*)p; float4* g4 = (float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adamw_one(pp.x, gg.x, mm.x, vv.x, a, coef);
+        adamw_one(pp.y, gg.y, mm.y, vv.y, a, coef);
+        adamw_one(pp.z, gg.z, mm.z, vv.z, a, coef);
+        adamw_one(pp.w, gg.w, mm.w, vv.w, a, coef);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (write_clipped_grad) g4[i] = make_float4(gg.x * coef, gg.y * coef, gg.z * coef, gg.w * coef);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adamw_one(pp, g[i], mm, vv, a, coef);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (write_clipped_grad) g[i] *= coef;
+    }
+}
+
+// ================================================================================================
+// C ABI
+static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)        \
+    do {                                              \
+        if ((dtype) == GA_DTYPE_BF16) { CALL_BF16; }  \
+        else if ((dtype) == GA_DTYPE_F32) { CALL_F32; } \
+        else return GA_ERR_ARG;                       \
+    } while (0)
+
+extern "C" {
+
+int ga_wn_scale(const float* v, const float* g, int rows, int n, float* scale, float* norm, hipStream_t s) {
+    if (!v || !g || !scale || !norm || rows <= 0 || n <= 0) return GA_ERR_ARG;
+    wn_scale_kernel<<<rows, 256, 0, s>>>(v, g, n, scale, norm);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+size_t ga_packed_elems(int mode, int D0, int D1, int K, int S) {
+    switch (mode) {
+        case GA_PACK_CONV_DGRAD_STRIDED: return (size_t)S * D1 * ((K + S - 1) / S) * D0;
+        default: return (size_t)D0 * D1 * K;
+    }
+}
+
+int ga_pack_weights(const float* src, const float* scale, void* dst, int dtype, int mode, int D0, int D1, int K, int S, int P,
+                    hipStream_t s) {
+    if (!src || !dst || D0 <= 0 || D1 <= 0 || K <= 0 || mode < 0 || mode > 4) return GA_ERR_ARG;
+    if ((mode == GA_PACK_CONV_DGRAD_STRIDED || mode == GA_PACK_CONVT_FWD) && S < 1) return GA_ERR_ARG;
+    if (mode == GA_PACK_CONVT_FWD && K != 2 * S) return GA_ERR_ARG;
+    const size_t n = (size_t)D0 * D1 * K;
+    const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
+    if (mode == GA_PACK_CONV_DGRAD_STRIDED) {
+        if (hipMemsetAsync(dst, 0, ga_packed_elems(mode, D0, D1, K, S) * esz, s) != hipSuccess) return GA_ERR_LAUNCH;
+    }
+    DISPATCH_T(dtype, (pack_weights_kernel<float><<<grid_for(n), 256, 0, s>>>(src, scale, (float*)dst, mode, D0, D1, K, S, P)),
+               (pack_weights_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>(src, scale, (bf16_t*)dst, mode, D0, D1, K, S, P)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_unpack_grad(const float* packed, float* dw, int mode, int D0, int D1, int K, int S, int P, int accumulate, hipStream_t s) {
+    if (!packed || !dw || D0 <= 0 || D1 <= 0 || K <= 0 || mode < 0 || mode > 4) return GA_ERR_ARG;
+    unpack_grad_kernel<<<grid_for((size_t)D0 * D1 * K), 256, 0, s>>>(packed, dw, mode, D0, D1, K, S, P, accumulate);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_wn_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows, int n, float* dv, float* dg,
+              int accumulate, hipStream_t s) {
+    if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || n <= 0) return GA_ERR_ARG;
+    wn_bwd_kernel<<<rows, 256, 0, s>>>(dw, v, g, norm, n, dv, dg, accumulate);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_gn_stats(const void* x, int dtype, int B, int T, int C, int G, float eps, float* mean, float* rstd, hipStream_t s) {
+    if (!x || !mean || !rstd || B <= 0 || T <= 0 || C <= 0 || G <= 0 || C % G) return GA_ERR_ARG;
+    DISPATCH_T(dtype, (gn_stats_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd)),
+               (gn_stats_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_gn_film_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* ab, const void* res, void* y, int dtype, int B, int T, int C, int G, int act, hipStream_t s) {
+    if (!x || !mean || !rstd || !gamma || !beta || !y || C % G) return GA_ERR_ARG;
+    const size_t n = (size_t)B * T * C;
+    DISPATCH_T(dtype,
+               (gn_film_act_fwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)x, mean, rstd, gamma, beta, ab, (const float*)res, (float*)y, B, T, C, G, act)),
+               (gn_film_act_fwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)x, mean, rstd, gamma, beta, ab, (const bf16_t*)res, (bf16_t*)y, B, T, C, G, act)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_gn_film_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* ab, void* dx, float* dgamma, float* dbeta, float* dab, int dtype, int B, int T, int C, int G,
+                       int act, hipStream_t s) {
+    if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || C % G) return GA_ERR_ARG;
+    if (C / G > 256 || (ab && !dab)) return GA_ERR_ARG;
+    DISPATCH_T(dtype,
+               (gn_film_act_bwd_kernel<float><<<B * G, 256, 0, s>>>((const float*)dy, (const float*)x, mean, rstd, gamma, beta, ab, (float*)dx, dgamma, dbeta, dab, T, C, G, act)),
+               (gn_film_act_bwd_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, beta, ab, (bf16_t*)dx, dgamma, dbeta, dab, T, C, G, act)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_tanh_residual_fwd(const void* raw, const void* q, void* y, int dtype, size_t n, float rscale, hipStream_t s) {
+    if (!raw || !q || !y) return GA_ERR_ARG;
+    DISPATCH_T(dtype, (tanh_residual_fwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)raw, (const float*)q, (float*)y, n, rscale)),
+               (tanh_residual_fwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)raw, (const bf16_t*)q, (bf16_t*)y, n, rscale)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_tanh_residual_bwd(const void* dy, const void* raw, void* draw, int dtype, size_t n, float rscale, hipStream_t s) {
+    if (!dy || !raw || !draw) return GA_ERR_ARG;
+    DISPATCH_T(dtype, (tanh_residual_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)dy, (const float*)raw, (float*)draw, n, rscale)),
+               (tanh_residual_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)raw, (bf16_t*)draw, n, rscale)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_avgpool1d_fwd(const void* x, void* y, int dtype, int B, int L, int Lo, hipStream_t s) {
+    if (!x || !y || B <= 0 || L <= 0 || Lo != (L + 2 - 4) / 2 + 1) return GA_ERR_ARG;
+    const size_t n = (size_t)B * Lo;
+    DISPATCH_T(dtype, (avgpool_fwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)x, (float*)y, B, L, Lo)),
+               (avgpool_fwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, B, L, Lo)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_avgpool1d_bwd(const void* dy, void* dx, int dtype, int B, int L, int Lo, hipStream_t s) {
+    if (!dy || !dx || B <= 0 || L <= 0 || Lo != (L + 2 - 4) / 2 + 1) return GA_ERR_ARG;
+    const size_t n = (size_t)B * L;
+    DISPATCH_T(dtype, (avgpool_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)dy, (float*)dx, B, L, Lo)),
+               (avgpool_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)dy, (bf16_t*)dx, B, L, Lo)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, int mode, hipStream_t s) {
+    if (!gy || !src || !ga) return GA_ERR_ARG;
+    DISPATCH_T(dtype, (act_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, n, mode)),
+               (act_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, n, mode)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s) {
+    if (!g || !out || M <= 0) return GA_ERR_ARG;
+    if (rows == 0) return GA_OK;
+    size_t blocks = (rows + 511) / 512;
+    if (blocks > 1024) blocks = 1024;
+    const size_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    DISPATCH_T(dtype, (colsum_kernel<float><<<(int)blocks, 256, 0, s>>>((const float*)g, rows, M, out, rpb)),
+               (colsum_kernel<bf16_t><<<(int)blocks, 256, 0, s>>>((const bf16_t*)g, rows, M, out, rpb)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_reduce(const void* a, const void* b, int dtype, size_t n, int op, float scale, float* out, hipStream_t s) {
+    if (!a || !out || op < 0 || op > 4 || (op == GA_RED_ABSDIFF && !b)) return GA_ERR_ARG;
+    if (n == 0) return GA_OK;
+    DISPATCH_T(dtype, (reduce_kernel<float><<<grid_for(n, 256, 1024), 256, 0, s>>>((const float*)a, (const float*)b, n, op, scale, out)),
+               (reduce_kernel<bf16_t><<<grid_for(n, 256, 1024), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, scale, out)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_reduce_grad(const void* a, const void* b, int dtype, size_t n, int op, const float* coef, float scale, void* ga,
+                   int accumulate, hipStream_t s) {
+    if (!a || !coef || !ga || op < 0 || op > 4 || (op == GA_RED_ABSDIFF && !b)) return GA_ERR_ARG;
+    if (n == 0) return GA_OK;
+    DISPATCH_T(dtype, (reduce_grad_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)a, (const float*)b, n, op, coef, scale, (float*)ga, accumulate)),
+               (reduce_grad_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, coef, scale, (bf16_t*)ga, accumulate)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_latent_loss_fwd(const void* qh, const void* qs, int dtype, int B, int T, int C, float* out, hipStream_t s) {
+    if (!qh || !qs || !out || B <= 0 || B > 65535 || T <= 0 || C <= 0) return GA_ERR_ARG;
+    const int gx = grid_for((size_t)T * C, 256, 64);
+    DISPATCH_T(dtype, (latent_loss_fwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)qh, (const float*)qs, T, C, out)),
+               (latent_loss_fwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)qh, (const bf16_t*)qs, T, C, out)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_latent_loss_bwd(const void* qh, const void* qs, int dtype, int B, int T, int C, const float* gout, void* dqh, hipStream_t s) {
+    if (!qh || !qs || !gout || !dqh || B <= 0 || T <= 0 || C <= 0) return GA_ERR_ARG;
+    const size_t n = (size_t)B * T * C;
+    DISPATCH_T(dtype, (latent_loss_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)qh, (const float*)qs, B, T, C, gout, (float*)dqh)),
+               (latent_loss_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)qh, (const bf16_t*)qs, B, T, C, gout, (bf16_t*)dqh)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_grad_sqnorm(const float* g, size_t n, float* out, hipStream_t s) {
+    if (!g || !out || ((uintptr_t)g & 15)) return g && out ? GA_ERR_ALIGN : GA_ERR_ARG;
+    if (n == 0) return GA_OK;
+    sqnorm_kernel<<<grid_for(n / 4 + 1, 256, 1024), 256, 0, s>>>(g, n, out);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_adamw_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float max_norm, float grad_scale, const float* sqnorm,
+                   int write_clipped_grad, hipStream_t s) {
+    if (!p || !g || !m || !v || step < 1) return GA_ERR_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return GA_ERR_ALIGN;
+    if (n == 0) return GA_OK;
+    AdamWArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step));
+    a.bc2 = (float)(1.0 - pow((double)beta2, step));
+    a.max_norm = max_norm; a.grad_scale = grad_scale;
+    adamw_kernel<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, s>>>(p, g, m, v, n, a, sqnorm, write_clipped_grad);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+}  // extern "C"

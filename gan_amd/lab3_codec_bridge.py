@@ -1,0 +1,195 @@
+"""MI355X-native frozen EnCodec (SEANet) decoder behind the reference's `FrozenEncodec.decode_embeddings`
+(/root/reference/lab 3/src/lab3_codec_bridge.py:135-146).
+
+The reference calls the third-party HF `EncodecDecoder` (transformers modeling_encodec.py:316-347).  Here the
+same layer stack runs on the gan_amd convolution kernels in channels-last layout:
+  EncodecConv1d (:76-176)          -> ops.ConvFrozen('cconv'): causal reflect pad fused into the window load
+  EncodecConvTranspose1d (:179-233)-> ops.ConvFrozen('convt'): one 2-tap GEMM phase per output residue, right trim implicit
+  ELU (:268,330,340)               -> fused as the consumer's load prologue (and ELU' in its data-gradient epilogue)
+  EncodecResnetBlock (:252-283)    -> shortcut conv, then k3 conv, then k1 conv whose epilogue adds the shortcut
+  EncodecLSTM (:236-249)           -> torch's LSTM op on ROCm (MIOpen); SURVEY.md section 8(f) lists a HIP LSTM as next-2
+Weights are frozen; only the gradient w.r.t. the input latents is produced.  `state_dict()` keys equal the HF
+decoder's, so `SeanetDecoder.load_state_dict(hf_model.decoder.state_dict())` is the integration step
+(loading the checkpoint itself, `EncodecModel.from_pretrained`, stays with the caller: it is a network fetch).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .lab3_codec_models import _act_dtype
+from .ops import ConvGeom
+
+
+class _WN(nn.Module):
+    """Holds parametrizations.weight.original0 / original1 (torch.nn.utils.parametrizations.weight_norm naming)."""
+
+    def __init__(self, g_shape, v_shape):
+        super().__init__()
+        self.parametrizations = nn.Module()
+        self.parametrizations.weight = nn.Module()
+        self.parametrizations.weight.original0 = nn.Parameter(torch.ones(g_shape), requires_grad=False)
+        self.parametrizations.weight.original1 = nn.Parameter(torch.randn(v_shape) * 0.05, requires_grad=False)
+
+    @property
+    def g(self):
+        return self.parametrizations.weight.original0
+
+    @property
+    def v(self):
+        return self.parametrizations.weight.original1
+
+
+class _ConvLayer(nn.Module):
+    def __init__(self, geom: ConvGeom):
+        super().__init__()
+        d0, d1, k = geom.wdims
+        self.conv = _WN((d0, 1, 1), (d0, d1, k))
+        self.conv.bias = nn.Parameter(torch.zeros(geom.cout), requires_grad=False)  # key: <layer>.conv.bias
+        self.geom = geom
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, dim: int, compress: int, k: int):
+        super().__init__()
+        hidden = dim // compress
+        self.block = nn.Module()
+        self.block.add_module("1", _ConvLayer(ConvGeom("cconv", dim, hidden, k)))
+        self.block.add_module("3", _ConvLayer(ConvGeom("cconv", hidden, dim, 1)))
+        self.shortcut = _ConvLayer(ConvGeom("cconv", dim, dim, 1))
+
+
+class _LSTM(nn.Module):
+    def __init__(self, dim: int, layers: int):
+        super().__init__()
+        self.lstm = nn.LSTM(dim, dim, layers)
+        for p in self.lstm.parameters():
+            p.requires_grad = False
+
+
+class SeanetDecoder(nn.Module):
+    """EncodecDecoder with EncodecConfig() defaults (24 kHz): ratios (8,5,4,2), 32 filters, 2 LSTM layers,
+    causal, reflect pad, weight_norm, 1 residual layer (dilation 1), compress 2, conv shortcut."""
+
+    def __init__(self, hidden_size: int = 128, num_filters: int = 32, ratios=(8, 5, 4, 2), kernel_size: int = 7,
+                 last_kernel_size: int = 7, residual_kernel_size: int = 3, compress: int = 2, lstm_layers: int = 2,
+                 precision: str = "fp32"):
+        super().__init__()
+        self.precision = precision
+        self.ratios = tuple(int(r) for r in ratios)
+        c = (2 ** len(self.ratios)) * num_filters
+        layers = nn.Module()
+        self._plan: List[Tuple[str, str]] = []
+        layers.add_module("0", _ConvLayer(ConvGeom("cconv", hidden_size, c, kernel_size)))
+        self._plan.append(("conv", "0"))
+        layers.add_module("1", _LSTM(c, lstm_layers))
+        self._plan.append(("lstm", "1"))
+        idx = 2
+        for r in self.ratios:
+            idx += 1  # ELU (fused into the transposed conv's load)
+            layers.add_module(str(idx), _ConvLayer(ConvGeom("convt", c, c // 2, 2 * r, r)))
+            self._plan.append(("elu_convt", str(idx)))
+            idx += 1
+            c //= 2
+            layers.add_module(str(idx), _ResBlock(c, compress, residual_kernel_size))
+            self._plan.append(("resblock", str(idx)))
+            idx += 1
+        idx += 1  # ELU
+        layers.add_module(str(idx), _ConvLayer(ConvGeom("cconv", num_filters, 1, last_kernel_size)))
+        self._plan.append(("elu_conv", str(idx)))
+        self.layers = layers
+        self._packs: Dict[Tuple[str, torch.dtype], Tuple[torch.Tensor, torch.Tensor]] = {}
+        for p in self.parameters():
+            p.requires_grad = False
+
+    # packed weights are cached: the decoder is frozen.  Call after loading / moving the module.
+    def invalidate_packs(self) -> None:
+        self._packs.clear()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_packs()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._packs = {}
+        return out
+
+    def _pack(self, name: str, layer: _ConvLayer, dtype):
+        key = (name, dtype)
+        if key not in self._packs:
+            self._packs[key] = ops.pack_frozen(layer.geom, layer.conv.v.data, layer.conv.g.data, dtype)
+        return self._packs[key]
+
+    def _conv(self, name: str, layer: _ConvLayer, x, dtype, pre_act=L.ACT_NONE, res=None):
+        wp_f, wp_d = self._pack(name, layer, dtype)
+        return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act)
+
+    def forward(self, q_bct: torch.Tensor) -> torch.Tensor:
+        """q [B, 128, T] -> wav [B, 1, T*prod(ratios)]"""
+        L.require_cuda(q_bct)
+        dtype = _act_dtype(self.precision)
+        h = q_bct.permute(0, 2, 1).to(dtype).contiguous()  # NLC
+        for kind, name in self._plan:
+            layer = getattr(self.layers, name)
+            if kind == "conv":
+                h = self._conv(name, layer, h, dtype)
+            elif kind == "lstm":
+                seq = h.permute(1, 0, 2).float()  # [T, B, C]
+                was_training = layer.lstm.training
+                layer.lstm.train(True)  # lab3_codec_bridge.py:140-145: RNN backward needs train mode
+                out, _ = layer.lstm(seq)
+                layer.lstm.train(was_training)
+                h = (out + seq).permute(1, 0, 2).to(dtype).contiguous()
+            elif kind == "elu_convt":
+                h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
+            elif kind == "resblock":
+                sc = self._conv(name + ".sc", layer.shortcut, h, dtype)
+                t = self._conv(name + ".b1", getattr(layer.block, "1"), h, dtype, pre_act=L.ACT_ELU)
+                h = self._conv(name + ".b3", getattr(layer.block, "3"), t, dtype, pre_act=L.ACT_ELU, res=sc)
+            elif kind == "elu_conv":
+                h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
+        return h.permute(0, 2, 1)  # [B, 1, S]
+
+
+@dataclass
+class CodecConfig:
+    """reference lab3_codec_bridge.py:15-24"""
+    model_id: str = "facebook/encodec_24khz"
+    sample_rate: int = 24000
+    chunk_seconds: float = 5.0
+    bandwidth: float = 6.0
+    codebook_size: int = 1024
+    num_codebooks: int = 8
+    latent_channels: int = 128
+    frame_rate: float = 75.0
+
+
+class FrozenEncodec:
+    """The part of the reference's FrozenEncodec that sits on the training hot path: `.cfg` and
+    `.decode_embeddings(q[B,C,T]) -> wav[B,1,S]`, differentiable w.r.t. q.  Construct it from an HF decoder
+    state dict (or leave the random init for synthetic benchmarks)."""
+
+    def __init__(self, decoder_state_dict: Optional[dict] = None, device: str = "cuda", precision: str = "fp32",
+                 chunk_seconds: float = 5.0):
+        self.device = device
+        self.decoder = SeanetDecoder(precision=precision)
+        if decoder_state_dict is not None:
+            self.decoder.load_state_dict(decoder_state_dict, strict=True)
+        self.decoder.to(device)
+        self.cfg = CodecConfig(chunk_seconds=float(chunk_seconds))
+
+    def decode_embeddings(self, q_emb_b_c_t: torch.Tensor) -> torch.Tensor:
+        return self.decoder(q_emb_b_c_t.to(self.device))
+
+    def expected_num_frames(self) -> int:
+        return int(round(float(self.cfg.chunk_seconds) * float(self.cfg.frame_rate)))
+
+    def target_num_samples(self) -> int:
+        return int(round(float(self.cfg.chunk_seconds) * float(self.cfg.sample_rate)))

@@ -1,0 +1,247 @@
+"""MI355X-native drop-in for the reference's `lab 3/src/lab3_codec_models.py`.
+
+Same class / function names, constructor and forward signatures, return structures and `state_dict()`
+keys as the reference (cited per symbol); the arithmetic runs in the HIP kernels behind gan_amd.ops.
+Tensors cross the API as [B, C, T] like the reference; inside, activations are channels-last [B, T, C]
+(the returned feature maps are [B, C, T]-shaped views of those buffers).  GPU only.
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .ops import ConvGeom
+
+_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _act_dtype(precision: str) -> torch.dtype:
+    if precision not in _DTYPES:
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    return _DTYPES[precision]
+
+
+def _to_nlc(x_bct: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[B, C, T] (any strides) -> contiguous [B, T, C] in the activation dtype (free when it already is)."""
+    return x_bct.permute(0, 2, 1).to(dtype).contiguous()
+
+
+class FiLM(nn.Module):
+    """reference lab3_codec_models.py:11-25.  The 2-layer MLP on the [B, cond] vector (0.4 MMAC) is a plain
+    library GEMM; the broadcast x*(1+a)+b is fused into the GroupNorm kernel (ops.GnFilmAct)."""
+
+    def __init__(self, cond_dim: int, n_channels: int):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(cond_dim, n_channels * 2), nn.SiLU(), nn.Linear(n_channels * 2, n_channels * 2))
+
+    def ab(self, cond: torch.Tensor) -> torch.Tensor:
+        return self.proj(cond)
+
+
+class ResidualFiLMBlock(nn.Module):
+    """reference lab3_codec_models.py:28-47 (parameter containers are the same torch modules => same keys/init)."""
+
+    def __init__(self, channels: int, cond_dim: int, dilation: int):
+        super().__init__()
+        self.conv1 = nn.Conv1d(channels, channels, kernel_size=3, padding=dilation, dilation=dilation)
+        self.conv2 = nn.Conv1d(channels, channels, kernel_size=3, padding=1)
+        self.norm1 = nn.GroupNorm(num_groups=8, num_channels=channels)
+        self.norm2 = nn.GroupNorm(num_groups=8, num_channels=channels)
+        self.film1 = FiLM(cond_dim=cond_dim, n_channels=channels)
+        self.film2 = FiLM(cond_dim=cond_dim, n_channels=channels)
+        self.g1 = ConvGeom("conv", channels, channels, 3, 1, dilation, dilation)
+        self.g2 = ConvGeom("conv", channels, channels, 3, 1, 1, 1)
+
+
+def _conv_train(x, conv: nn.Conv1d, geom: ConvGeom, dtype, post_act=L.ACT_NONE, weight_g=None, weight_v=None):
+    v = conv.weight if weight_v is None else weight_v
+    wp_f, wp_d, carrier = ops.PackTrainable.apply(v, weight_g, geom, dtype)
+    return ops.ConvTrain.apply(x, wp_f, wp_d, carrier, conv.bias, geom, post_act)
+
+
+class CodecLatentTranslator(nn.Module):
+    """reference lab3_codec_models.py:50-119: FiLM-conditioned dilated Conv1d ResNet on codec latents."""
+
+    def __init__(self, in_channels: int = 128, z_content_dim: int = 128, z_style_dim: int = 128, hidden_channels: int = 256,
+                 n_blocks: int = 10, noise_dim: int = 32, residual_scale: float = 0.5, direct_output: bool = False,
+                 precision: str = "fp32"):
+        super().__init__()
+        self.in_channels = int(in_channels)
+        self.z_content_dim = int(z_content_dim)
+        self.z_style_dim = int(z_style_dim)
+        self.noise_dim = int(noise_dim)
+        self.residual_scale = float(residual_scale)
+        self.direct_output = bool(direct_output)
+        self.precision = precision
+        cond_dim = self.z_content_dim + self.z_style_dim + self.noise_dim
+        self.in_proj = nn.Conv1d(self.in_channels, hidden_channels, kernel_size=3, padding=1)
+        dilations = [1, 2, 4, 8, 1, 2, 4, 8, 1, 2]
+        if int(n_blocks) != len(dilations):
+            dilations = [2 ** (i % 4) for i in range(int(n_blocks))]
+        self.blocks = nn.ModuleList([ResidualFiLMBlock(hidden_channels, cond_dim, int(d)) for d in dilations])
+        self.out_norm = nn.GroupNorm(num_groups=8, num_channels=hidden_channels)
+        self.out_proj = nn.Conv1d(hidden_channels, self.in_channels, kernel_size=3, padding=1)
+        self._g_in = ConvGeom("conv", self.in_channels, hidden_channels, 3, 1, 1, 1)
+        self._g_out = ConvGeom("conv", hidden_channels, self.in_channels, 3, 1, 1, 1)
+
+    def sample_noise(self, batch_size: int, device: torch.device) -> torch.Tensor:
+        return torch.randn(batch_size, self.noise_dim, device=device)
+
+    def forward(self, q_src: torch.Tensor, z_content: torch.Tensor, z_style_tgt: torch.Tensor,
+                noise: Optional[torch.Tensor] = None, style_dropout_p: float = 0.0, style_jitter_std: float = 0.0) -> torch.Tensor:
+        L.require_cuda(q_src)
+        dtype = _act_dtype(self.precision)
+        b = int(q_src.shape[0])
+        if noise is None:
+            noise = torch.zeros((b, self.noise_dim), device=q_src.device, dtype=torch.float32)
+        zs = z_style_tgt
+        if style_dropout_p > 0.0:
+            keep = (torch.rand((b, 1), device=q_src.device) >= float(style_dropout_p)).to(zs.dtype)
+            zs = zs * keep
+        if style_jitter_std > 0.0:
+            zs = zs + torch.randn_like(zs) * float(style_jitter_std)
+        cond = torch.cat([z_content, zs, noise], dim=1).float()
+
+        q = _to_nlc(q_src, dtype)
+        h = _conv_train(q, self.in_proj, self._g_in, dtype)
+        for blk in self.blocks:
+            r = _conv_train(h, blk.conv1, blk.g1, dtype)
+            r = ops.GnFilmAct.apply(r, blk.norm1.weight, blk.norm1.bias, blk.film1.ab(cond), None, 8, L.ACT_SILU, blk.norm1.eps)
+            r = _conv_train(r, blk.conv2, blk.g2, dtype)
+            h = ops.GnFilmAct.apply(r, blk.norm2.weight, blk.norm2.bias, blk.film2.ab(cond), h, 8, L.ACT_SILU, blk.norm2.eps)
+        h = ops.GnFilmAct.apply(h, self.out_norm.weight, self.out_norm.bias, None, None, 8, L.ACT_SILU, self.out_norm.eps)
+        raw = _conv_train(h, self.out_proj, self._g_out, dtype)
+        if self.direct_output:
+            return raw.permute(0, 2, 1)
+        return ops.TanhResidual.apply(raw, q, self.residual_scale).permute(0, 2, 1)
+
+
+class WaveDiscBlock(nn.Module):
+    """reference lab3_codec_models.py:122-128: weight_norm(Conv1d) + leaky_relu(0.2), fused into one kernel epilogue."""
+
+    def __init__(self, in_ch: int, out_ch: int, k: int, s: int, p: int):
+        super().__init__()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.conv = nn.utils.weight_norm(nn.Conv1d(in_ch, out_ch, kernel_size=k, stride=s, padding=p))
+        self.geom = ConvGeom("conv", in_ch, out_ch, k, s, p, 1)
+
+    def run(self, x_nlc: torch.Tensor, act: int) -> torch.Tensor:
+        return _conv_train(x_nlc, self.conv, self.geom, x_nlc.dtype, act, self.conv.weight_g, self.conv.weight_v)
+
+
+class SingleScaleWaveDiscriminator(nn.Module):
+    """reference lab3_codec_models.py:131-152"""
+
+    def __init__(self):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            WaveDiscBlock(1, 32, 15, 1, 7),
+            WaveDiscBlock(32, 64, 41, 4, 20),
+            WaveDiscBlock(64, 128, 41, 4, 20),
+            WaveDiscBlock(128, 256, 41, 4, 20),
+            WaveDiscBlock(256, 512, 41, 4, 20),
+        ])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.out = nn.utils.weight_norm(nn.Conv1d(512, 1, kernel_size=3, stride=1, padding=1))
+        self._g_out = ConvGeom("conv", 512, 1, 3, 1, 1, 1)
+
+    def forward_nlc(self, x: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        feats: List[torch.Tensor] = []
+        h = x
+        for blk in self.blocks:
+            h = blk.run(h, L.ACT_LRELU)
+            feats.append(h)
+        logits = _conv_train(h, self.out, self._g_out, h.dtype, L.ACT_NONE, self.out.weight_g, self.out.weight_v)
+        return logits, feats
+
+    def forward(self, wav: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        logits, feats = self.forward_nlc(wav.permute(0, 2, 1).contiguous())
+        return logits.permute(0, 2, 1), [f.permute(0, 2, 1) for f in feats]
+
+
+class MultiScaleWaveDiscriminator(nn.Module):
+    """reference lab3_codec_models.py:155-168"""
+
+    def __init__(self, n_scales: int = 3, precision: str = "fp32"):
+        super().__init__()
+        self.discs = nn.ModuleList([SingleScaleWaveDiscriminator() for _ in range(int(n_scales))])
+        self.pool = nn.AvgPool1d(kernel_size=4, stride=2, padding=1)  # parameter-free; kept for attribute parity
+        self.precision = precision
+
+    def forward(self, wav: torch.Tensor) -> List[Tuple[torch.Tensor, List[torch.Tensor]]]:
+        L.require_cuda(wav)
+        dtype = _act_dtype(self.precision)
+        if wav.dim() != 3 or wav.shape[1] != 1:
+            raise ValueError(f"expected wav [B, 1, S], got {tuple(wav.shape)}")
+        outs: List[Tuple[torch.Tensor, List[torch.Tensor]]] = []
+        x = wav[:, 0, :].to(dtype)  # [B, S]; with C == 1 the NLC and NCL layouts coincide
+        for i, d in enumerate(self.discs):
+            if i > 0:
+                x = ops.AvgPool4s2.apply(x)
+            logits, feats = d.forward_nlc(x.unsqueeze(-1))
+            outs.append((logits.permute(0, 2, 1), [f.permute(0, 2, 1) for f in feats]))
+        return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# losses (reference lab3_codec_models.py:171-215); means are sums from the reduction kernels / numel
+def hinge_d_loss(real_logits: torch.Tensor, fake_logits: torch.Tensor) -> torch.Tensor:
+    return (ops.reduce_sum(real_logits, None, L.RED_RELU1M) / real_logits.numel()
+            + ops.reduce_sum(fake_logits, None, L.RED_RELU1P) / fake_logits.numel())
+
+
+def hinge_g_loss(fake_logits: torch.Tensor) -> torch.Tensor:
+    return -ops.reduce_sum(fake_logits, None, L.RED_SUM) / fake_logits.numel()
+
+
+def feature_matching_loss(real_feats: Sequence[torch.Tensor], fake_feats: Sequence[torch.Tensor]) -> torch.Tensor:
+    loss = torch.zeros((), device=fake_feats[0].device)
+    for a, b in zip(real_feats, fake_feats):
+        # F.l1_loss(a.detach(), b): the gradient goes to the fake features only
+        loss = loss + ops.reduce_sum(b, a.detach(), L.RED_ABSDIFF) / b.numel()
+    return loss / max(1, len(fake_feats))
+
+
+def multiscale_hinge_d_loss(real_outs, fake_outs) -> torch.Tensor:
+    loss = torch.zeros((), device=real_outs[0][0].device)
+    for (real_logits, _), (fake_logits, _) in zip(real_outs, fake_outs):
+        loss = loss + hinge_d_loss(real_logits, fake_logits)
+    return loss / max(1, len(real_outs))
+
+
+def multiscale_hinge_g_loss(fake_outs) -> torch.Tensor:
+    loss = torch.zeros((), device=fake_outs[0][0].device)
+    for fake_logits, _ in fake_outs:
+        loss = loss + hinge_g_loss(fake_logits)
+    return loss / max(1, len(fake_outs))
+
+
+def multiscale_feature_matching_loss(real_outs, fake_outs) -> torch.Tensor:
+    loss = torch.zeros((), device=fake_outs[0][0].device)
+    for (_, rf), (_, ff) in zip(real_outs, fake_outs):
+        loss = loss + feature_matching_loss(rf, ff)
+    return loss / max(1, len(real_outs))
+
+
+@dataclass
+class CodecTrainWeights:
+    """reference lab3_codec_models.py:218-229"""
+    adv: float = 0.5
+    latent_l1: float = 4.0
+    latent_continuity: float = 1.0
+    content: float = 2.0
+    style: float = 3.0
+    mrstft: float = 2.0
+    feature_match: float = 1.0
+    mode_seeking: float = 0.0
+    style_push: float = 0.0
+    delta_budget: float = 0.0

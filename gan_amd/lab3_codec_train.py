@@ -1,0 +1,395 @@
+"""MI355X-native drop-in for the hot-path part of the reference's `lab 3/src/lab3_codec_train.py`.
+
+Mirrors (same names / signatures / return structures):
+  CodecStageTrainConfig (:25-56), build_style_centroid_bank / build_style_exemplar_bank / build_q_exemplar_bank (:59-87),
+  _sample_shift_targets(_balanced) (:90-106), _sample_bank_rows (:109-118), _mix_style_condition (:121-145),
+  _waveform_mrstft_loss (:148-176), _save_stage_checkpoint / _try_load_stage_checkpoint (:225-264),
+  train_codec_stage (:267-648).
+The loop body lives in `codec_train_iteration`, which takes the per-iteration random picks as explicit tensors so
+that parity tests can inject them.  Loss terms covered: adv, feature matching, latent L1, continuity, MR-STFT,
+delta budget, mode seeking.  The Lab1 content term and the judge/probe style terms need modules outside this
+path and raise NotImplementedError when requested.
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .lab3_codec_models import (CodecLatentTranslator, CodecTrainWeights, MultiScaleWaveDiscriminator,
+                                multiscale_feature_matching_loss, multiscale_hinge_d_loss, multiscale_hinge_g_loss)
+from .optim import FusedAdamW
+
+
+@dataclass
+class CodecStageTrainConfig:
+    stage_name: str
+    epochs: int
+    lr_g: float = 2e-4
+    lr_d: float = 2e-4
+    betas: Tuple[float, float] = (0.5, 0.999)
+    max_batches_per_epoch: Optional[int] = None
+    target_balance: bool = True
+    cond_mode: str = "mix"  # centroid | exemplar | mix
+    cond_alpha_start: float = 0.8
+    cond_alpha_end: float = 0.4
+    style_dropout_p: float = 0.0
+    style_jitter_std: float = 0.0
+    exemplar_noise_std: float = 0.03
+    d_step_period: int = 1
+    r1_gamma: float = 0.0
+    r1_interval: int = 16
+    g_grad_clip_norm: float = 0.0
+    d_grad_clip_norm: float = 0.0
+    weights: CodecTrainWeights = field(default_factory=CodecTrainWeights)
+    mode_seeking_noise_scale: float = 1.0
+    mode_seeking_target: float = 0.03
+    style_push_margin: float = 0.30
+    delta_budget: float = 0.12
+    style_loss_mode: str = "lab1_cos"
+    style_embed_align_weight: float = 0.0
+    wave_mrstft_resolutions: Tuple[Tuple[int, int, int], ...] = ((512, 128, 512), (1024, 256, 1024), (2048, 512, 2048))
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side bank helpers (numpy / CPU torch, as in the reference: they run once per stage or per row)
+def build_style_centroid_bank(z_style: np.ndarray, genre_idx: np.ndarray, n_genres: int) -> torch.Tensor:
+    bank = np.zeros((int(n_genres), z_style.shape[1]), dtype=np.float32)
+    for g in range(int(n_genres)):
+        sel = genre_idx == g
+        if sel.any():
+            c = z_style[sel].mean(axis=0).astype(np.float32)
+            bank[g] = c / (np.linalg.norm(c) + 1e-8)
+    return torch.from_numpy(bank)
+
+
+def build_style_exemplar_bank(z_style: np.ndarray, genre_idx: np.ndarray, n_genres: int) -> Dict[int, torch.Tensor]:
+    bank: Dict[int, torch.Tensor] = {}
+    for g in range(int(n_genres)):
+        sel = genre_idx == g
+        if sel.any():
+            rows = z_style[sel].astype(np.float32)
+            bank[int(g)] = torch.from_numpy(rows / (np.linalg.norm(rows, axis=1, keepdims=True) + 1e-8))
+    return bank
+
+
+def build_q_exemplar_bank(q_emb: np.ndarray, genre_idx: np.ndarray, n_genres: int) -> Dict[int, torch.Tensor]:
+    bank: Dict[int, torch.Tensor] = {}
+    for g in range(int(n_genres)):
+        sel = genre_idx == g
+        if sel.any():
+            bank[int(g)] = torch.from_numpy(q_emb[sel].astype(np.float32))
+    return bank
+
+
+def _sample_shift_targets(source_idx: torch.Tensor, n_genres: int) -> torch.Tensor:
+    tgt = torch.randint(low=0, high=int(n_genres), size=(int(source_idx.shape[0]),), device=source_idx.device)
+    clash = tgt == source_idx
+    if clash.any():
+        tgt[clash] = (tgt[clash] + 1) % int(n_genres)
+    return tgt
+
+
+def _sample_shift_targets_balanced(source_idx: torch.Tensor, n_genres: int, offset: int = 0) -> torch.Tensor:
+    n = int(source_idx.shape[0])
+    tgt = (torch.arange(n, device=source_idx.device, dtype=torch.long) + int(offset)) % int(n_genres)
+    clash = tgt == source_idx
+    if clash.any():
+        tgt[clash] = (tgt[clash] + 1) % int(n_genres)
+    return tgt
+
+
+def _sample_bank_rows(bank: Dict[int, torch.Tensor], labels: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """One CPU-RNG randint per row, in label order (reference :109-118) so seeds reproduce the same picks."""
+    picked: List[torch.Tensor] = []
+    for lab in labels.detach().cpu().tolist():
+        rows = bank.get(int(lab))
+        if rows is None or rows.shape[0] == 0:
+            rows = bank[sorted(bank.keys())[0]]
+        i = int(torch.randint(low=0, high=int(rows.shape[0]), size=(1,)).item())
+        picked.append(rows[i:i + 1])
+    return torch.cat(picked, dim=0).to(device)
+
+
+def _mix_style_condition(target_idx: torch.Tensor, cond_mode: str, alpha: float, centroid_bank: torch.Tensor,
+                         exemplar_bank: Optional[Dict[int, torch.Tensor]], device: torch.device,
+                         exemplar_noise_std: float) -> torch.Tensor:
+    z_cent = centroid_bank[target_idx].to(device)
+    if exemplar_bank is None or len(exemplar_bank) == 0:
+        z_ex = z_cent
+    else:
+        z_ex = _sample_bank_rows(exemplar_bank, target_idx, device=device)
+    if exemplar_noise_std > 0.0:
+        z_ex = z_ex + torch.randn_like(z_ex) * float(exemplar_noise_std)
+    mode = str(cond_mode).strip().lower()
+    if mode == "centroid":
+        z = z_cent
+    elif mode == "exemplar":
+        z = z_ex
+    else:
+        z = float(alpha) * z_cent + (1.0 - float(alpha)) * z_ex
+    return F.normalize(z, dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+def _safe_sqrt(s: torch.Tensor) -> torch.Tensor:
+    pos = s > 0
+    return torch.where(pos, s, torch.ones_like(s)).sqrt() * pos
+
+
+def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolutions: Iterable[Tuple[int, int, int]],
+                          sum_hook=None) -> torch.Tensor:
+    """reference :148-176.  Per resolution one fused pass yields [sum (my-mx)^2, sum my^2, sum |log mx - log my|];
+    `sum_hook` (data parallel) may all-reduce those sums so the spectral-convergence ratio is the global-batch one."""
+    if wav_pred.shape != wav_true.shape:
+        raise ValueError(f"Shape mismatch: {tuple(wav_pred.shape)} vs {tuple(wav_true.shape)}")
+    L.require_cuda(wav_pred, wav_true)
+    x = wav_pred.squeeze(1)
+    y = wav_true.squeeze(1).detach()
+    B, S = x.shape
+    total = torch.zeros((), device=x.device)
+    used = 0
+    for n_fft, hop, win in resolutions:
+        n_fft, hop, win = int(n_fft), int(hop), int(win)
+        if S < n_fft:
+            continue
+        sums = ops.StftSums.apply(x, y, n_fft, hop, win, True)
+        count = float(B * (n_fft // 2 + 1) * (1 + S // hop))
+        if sum_hook is not None:
+            sums, count = sum_hook(sums, count)
+        sc = _safe_sqrt(sums[0]) / (_safe_sqrt(sums[1]) + 1e-8)
+        lm = sums[2] / count
+        total = total + sc + lm
+        used += 1
+    if used == 0:
+        return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF) / wav_pred.numel()
+    return total / float(used)
+
+
+# ------------------------------------------------------------------------------------------------
+def _save_stage_checkpoint(ckpt_path: Path, epoch: int, generator, discriminator, opt_g, opt_d, meta: Dict) -> None:
+    ckpt_path.parent.mkdir(parents=True, exist_ok=True)
+    payload = {"epoch": int(epoch), "generator": generator.state_dict(), "discriminator": discriminator.state_dict(),
+               "opt_g": opt_g.state_dict(), "opt_d": opt_d.state_dict(), "meta": dict(meta)}
+    torch.save(payload, str(ckpt_path))
+
+
+def _try_load_stage_checkpoint(ckpt_path: Path, generator, discriminator, opt_g, opt_d, device) -> int:
+    if not ckpt_path.exists():
+        return 0
+    payload = torch.load(str(ckpt_path), map_location=device, weights_only=False)  # file written by this code
+    generator.load_state_dict(payload["generator"], strict=True)
+    discriminator.load_state_dict(payload["discriminator"], strict=True)
+    opt_g.load_state_dict(payload["opt_g"])
+    opt_d.load_state_dict(payload["opt_d"])
+    return int(payload.get("epoch", 0))
+
+
+# ------------------------------------------------------------------------------------------------
+def latent_losses(q_hat: torch.Tensor, q_src: torch.Tensor, delta_budget: float):
+    """(latent L1, first-difference L1, delta-budget hinge) of reference :464-465,552-553 from one fused pass."""
+    B, Cn, T = q_hat.shape
+    qh = q_hat.permute(0, 2, 1)
+    qs = q_src.permute(0, 2, 1).to(qh.dtype)
+    sums = ops.LatentSums.apply(qh, qs)
+    l1 = sums[0] / float(B * Cn * T)
+    cont = sums[1] / float(B * Cn * max(T - 1, 1))
+    delta_mean = sums[2:] / float(Cn * T)
+    budget = F.relu(delta_mean - float(delta_budget)).mean()
+    return l1, cont, budget
+
+
+def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTranslator,
+                          discriminator: MultiScaleWaveDiscriminator, codec, opt_g: FusedAdamW, opt_d: FusedAdamW,
+                          q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
+                          q_real_tgt: Optional[torch.Tensor], q_real_tgt_g: torch.Tensor, global_step: int,
+                          noise2: Optional[torch.Tensor] = None, dp=None) -> Dict[str, torch.Tensor]:
+    """One iteration of the reference loop body (:404-591).  Returns device scalars (no host sync)."""
+    device = q_src.device
+    out: Dict[str, torch.Tensor] = {}
+    q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
+                      style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+    x_hat = codec.decode_embeddings(q_hat)
+    with torch.no_grad():
+        x_src = codec.decode_embeddings(q_src)
+
+    take_d_step = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
+    if take_d_step:
+        with torch.no_grad():
+            x_real = codec.decode_embeddings(q_real_tgt)
+        x_real = x_real.detach().requires_grad_(float(stage_cfg.r1_gamma) > 0.0)
+        real_outs = discriminator(x_real)
+        fake_outs_d = discriminator(x_hat.detach())
+        loss_d = multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d)
+        do_r1 = float(stage_cfg.r1_gamma) > 0.0 and (global_step % max(1, int(stage_cfg.r1_interval)) == 0)
+        opt_d.zero_grad(set_to_none=True)
+        loss_d_total = loss_d.detach()
+        if do_r1:
+            # R1 = E||d(sum_s mean logits_s)/dx_real||^2 (:429-442).  Instead of autograd's create_graph double
+            # backward, gan_amd/r1.py runs the second-order pass explicitly with the same conv kernels and
+            # accumulates 0.5*gamma*dR1/dtheta into the parameters' .grad; loss_d.backward() then adds the hinge part.
+            from .r1 import r1_penalty_and_grads
+            r1 = r1_penalty_and_grads(discriminator, x_real, real_outs, 0.5 * float(stage_cfg.r1_gamma))
+            out["r1"] = r1
+            loss_d_total = loss_d_total + 0.5 * float(stage_cfg.r1_gamma) * r1
+        loss_d.backward()
+        opt_d.max_grad_norm = float(stage_cfg.d_grad_clip_norm)
+        opt_d.gather_grads()
+        if dp is not None:
+            dp.allreduce_flat(opt_d)
+        opt_d.step(grads_gathered=True)
+        out["loss_d"] = loss_d_total
+        out["d_grad_norm"] = opt_d.last_grad_norm
+
+    q_real = q_real_tgt_g
+    with torch.no_grad():
+        x_real_g = codec.decode_embeddings(q_real)
+        real_outs_g = discriminator(x_real_g)
+    # D's own gradients from the G step are discarded by the reference (zero_grad(set_to_none) at :444 before they
+    # are ever used), so the fake pass runs with D's parameters frozen: no D weight-gradient kernels are launched.
+    d_params = [p for p in discriminator.parameters()]
+    saved = [p.requires_grad for p in d_params]
+    for p in d_params:
+        p.requires_grad_(False)
+    try:
+        fake_outs = discriminator(x_hat)
+    finally:
+        for p, r in zip(d_params, saved):
+            p.requires_grad_(r)
+
+    loss_adv = multiscale_hinge_g_loss(fake_outs=fake_outs)
+    loss_fm = multiscale_feature_matching_loss(real_outs=real_outs_g, fake_outs=fake_outs)
+    loss_lat_l1, loss_lat_cont, loss_delta_budget = latent_losses(q_hat, q_src, float(stage_cfg.delta_budget))
+    loss_mrstft = _waveform_mrstft_loss(wav_pred=x_hat, wav_true=x_src, resolutions=stage_cfg.wave_mrstft_resolutions,
+                                        sum_hook=None if dp is None else dp.stft_sum_hook)
+    zero = torch.zeros((), device=device)
+    loss_content = zero
+    loss_style = zero
+    loss_style_push = zero
+    loss_ms = zero
+    w = stage_cfg.weights
+    if float(w.mode_seeking) > 0.0:
+        if noise2 is None:
+            noise2 = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
+        noise2 = noise2 * float(stage_cfg.mode_seeking_noise_scale)
+        q_hat2 = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise2,
+                           style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+        num = ops.reduce_sum(q_hat, q_hat2, L.RED_ABSDIFF) / q_hat.numel()  # latent-space mode seeking (:567-571)
+        den = torch.mean(torch.abs(noise - noise2)).clamp_min(1e-5)
+        loss_ms = F.relu(float(stage_cfg.mode_seeking_target) - num / den)
+
+    loss_g = (float(w.adv) * loss_adv + float(w.feature_match) * loss_fm + float(w.latent_l1) * loss_lat_l1
+              + float(w.latent_continuity) * loss_lat_cont + float(w.mrstft) * loss_mrstft
+              + float(w.mode_seeking) * loss_ms + float(w.delta_budget) * loss_delta_budget)
+    opt_g.zero_grad(set_to_none=True)
+    loss_g.backward()
+    opt_g.max_grad_norm = float(stage_cfg.g_grad_clip_norm)
+    opt_g.gather_grads()
+    if dp is not None:
+        dp.allreduce_flat(opt_g)
+    opt_g.step(grads_gathered=True)
+
+    out.update(loss_g=loss_g.detach(), loss_adv=loss_adv.detach(), loss_fm=loss_fm.detach(),
+               loss_lat_l1=loss_lat_l1.detach(), loss_lat_cont=loss_lat_cont.detach(), loss_mrstft=loss_mrstft.detach(),
+               loss_delta_budget=loss_delta_budget.detach(), loss_ms=loss_ms.detach(), loss_content=loss_content,
+               loss_style=loss_style, loss_style_push=loss_style_push, g_grad_norm=opt_g.last_grad_norm,
+               q_hat=q_hat.detach(), x_hat=x_hat.detach())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTranslator,
+                      discriminator: MultiScaleWaveDiscriminator, codec, lab1_encoder, style_judge, train_loader, n_genres: int,
+                      style_centroid_bank: torch.Tensor, style_exemplar_bank: Optional[Dict[int, torch.Tensor]],
+                      q_exemplar_bank: Dict[int, torch.Tensor], out_ckpt_dir: Path, device: torch.device, resume: bool = False,
+                      lab1_probe=None, mert_probe=None, dp=None) -> List[Dict]:
+    """reference :267-648.  Same arguments and the same 19-key history rows.  Losses are accumulated on the device and
+    read back once per epoch (the reference syncs 12 scalars per iteration, :593-604)."""
+    w = stage_cfg.weights
+    if lab1_encoder is not None or style_judge is not None or lab1_probe is not None or mert_probe is not None:
+        raise NotImplementedError("content / style terms (Lab1 encoder, style judge, probes) are outside the accelerated "
+                                  "path; pass None (SURVEY.md section 8(f) next-1)")
+    if float(w.content) > 0.0 or float(w.style) > 0.0 or float(w.style_push) > 0.0:
+        warnings.warn("content / style / style_push weights are ignored: those terms are not part of this path", stacklevel=2)
+    generator.train()
+    discriminator.train()
+    style_centroid_bank = style_centroid_bank.to(device)
+    out_ckpt_dir = Path(out_ckpt_dir)
+    opt_g = FusedAdamW(generator.parameters(), lr=float(stage_cfg.lr_g), betas=stage_cfg.betas)
+    opt_d = FusedAdamW(discriminator.parameters(), lr=float(stage_cfg.lr_d), betas=stage_cfg.betas)
+    ckpt_path = out_ckpt_dir / f"{stage_cfg.stage_name}_latest.pt"
+    start_epoch = 0
+    if resume:
+        start_epoch = _try_load_stage_checkpoint(ckpt_path, generator, discriminator, opt_g, opt_d, device)
+
+    hist_rows: List[Dict] = []
+    global_step = 0
+    keys = ("loss_g", "loss_d", "loss_adv", "loss_fm", "loss_lat_l1", "loss_lat_cont", "loss_content", "loss_style",
+            "loss_style_push", "loss_delta_budget", "loss_mrstft", "loss_ms")
+    for epoch in range(start_epoch + 1, int(stage_cfg.epochs) + 1):
+        alpha = float(stage_cfg.cond_alpha_start)
+        if int(stage_cfg.epochs) > 1:
+            ratio = float(epoch - 1) / float(max(1, int(stage_cfg.epochs) - 1))
+            alpha += (float(stage_cfg.cond_alpha_end) - float(stage_cfg.cond_alpha_start)) * ratio
+        acc = {k: torch.zeros((), device=device) for k in keys}
+        d_steps_taken = d_steps_skipped = n_batches = 0
+        for bi, batch in enumerate(train_loader):
+            if stage_cfg.max_batches_per_epoch is not None and bi >= int(stage_cfg.max_batches_per_epoch):
+                break
+            global_step += 1
+            n_batches += 1
+            q_src = batch["q_emb"].to(device, non_blocking=True).float()
+            zc_src = F.normalize(batch["z_content"].to(device, non_blocking=True).float(), dim=-1)
+            zs_src = F.normalize(batch["z_style"].to(device, non_blocking=True).float(), dim=-1)
+            src_genre_idx = batch["genre_idx"].to(device, non_blocking=True).long()
+            if str(stage_cfg.stage_name) == "stage1":
+                tgt_genre_idx = src_genre_idx
+            elif bool(stage_cfg.target_balance):
+                tgt_genre_idx = _sample_shift_targets_balanced(src_genre_idx, n_genres=int(n_genres), offset=epoch + bi)
+            else:
+                tgt_genre_idx = _sample_shift_targets(src_genre_idx, n_genres=int(n_genres))
+            z_style_tgt = _mix_style_condition(tgt_genre_idx, str(stage_cfg.cond_mode), float(alpha), style_centroid_bank,
+                                               style_exemplar_bank, device, float(stage_cfg.exemplar_noise_std))
+            if (str(stage_cfg.stage_name) == "stage1" and str(stage_cfg.style_loss_mode).strip().lower() == "lab1_cos"
+                    and int(z_style_tgt.shape[1]) == int(zs_src.shape[1])):
+                z_style_tgt = zs_src
+            noise = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
+            take_d = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
+            q_real_tgt = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float() if take_d else None
+            q_real_tgt_g = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float()
+            res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, q_src, zc_src, z_style_tgt,
+                                        noise, q_real_tgt, q_real_tgt_g, global_step, dp=dp)
+            if take_d:
+                d_steps_taken += 1
+            else:
+                d_steps_skipped += 1
+            for k in keys:
+                if k in res:
+                    acc[k] += res[k].reshape(())
+        n = max(1, n_batches)
+        host = {k: float(v) for k, v in acc.items()}  # one sync per epoch
+        row = {
+            "stage": str(stage_cfg.stage_name), "epoch": int(epoch), "loss_g": host["loss_g"] / n,
+            "loss_d": (host["loss_d"] / max(1, d_steps_taken)) if d_steps_taken > 0 else 0.0,
+            "loss_adv": host["loss_adv"] / n, "loss_feature_match": host["loss_fm"] / n,
+            "loss_latent_l1": host["loss_lat_l1"] / n, "loss_continuity": host["loss_lat_cont"] / n,
+            "loss_content": host["loss_content"] / n, "loss_style": host["loss_style"] / n, "loss_style_embed": 0.0,
+            "loss_style_push": host["loss_style_push"] / n, "loss_delta_budget": host["loss_delta_budget"] / n,
+            "loss_mrstft": host["loss_mrstft"] / n, "loss_mode_seeking": host["loss_ms"] / n,
+            "d_steps_taken": int(d_steps_taken), "d_steps_skipped": int(d_steps_skipped),
+            "d_step_rate": float(d_steps_taken) / float(max(1, d_steps_taken + d_steps_skipped)), "cond_alpha": float(alpha),
+        }
+        print("[codec-train]" f" stage={row['stage']} epoch={row['epoch']} loss_g={row['loss_g']:.4f} loss_d={row['loss_d']:.4f}"
+              f" content={row['loss_content']:.4f} style={row['loss_style']:.4f} d_rate={row['d_step_rate']:.2f}")
+        hist_rows.append(row)
+        if dp is None or dp.rank == 0:
+            _save_stage_checkpoint(ckpt_path, int(epoch), generator, discriminator, opt_g, opt_d,
+                                   {"stage": str(stage_cfg.stage_name), "config": stage_cfg.__dict__})
+    return hist_rows

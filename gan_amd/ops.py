@@ -1,0 +1,581 @@
+"""Autograd operators of the lab3 codec GAN step, each a thin wrapper over the C ABI (include/gan_amd.h).
+
+All activations are channels-last [B, L, C] ("NLC") CUDA tensors in float32 or bfloat16; parameters,
+their gradients and loss sums are float32.  PyTorch supplies device memory, streams and the autograd
+tape - every O(N) computation happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+# ================================================================================================
+# geometry of one Conv1d / ConvTranspose1d layer and its three GEMM forms
+@dataclass(frozen=True)
+class ConvGeom:
+    """kind 'conv': Conv1d(cin, cout, k, stride, padding, dilation), zero padding
+       kind 'cconv': causal reflect-padded stride-1 conv (HF EncodecConv1d, modeling_encodec.py:157-176)
+       kind 'convt': causal ConvTranspose1d(cin, cout, k=2*stride, stride) with the right trim (:206-233)"""
+    kind: str
+    cin: int
+    cout: int
+    k: int
+    stride: int = 1
+    padding: int = 0
+    dilation: int = 1
+
+    def out_len(self, lin: int) -> int:
+        if self.kind == "conv":
+            return (lin + 2 * self.padding - self.dilation * (self.k - 1) - 1) // self.stride + 1
+        if self.kind == "cconv":
+            return lin
+        return lin * self.stride
+
+    # weight source dims (D0, D1, K) as stored in the parameter
+    @property
+    def wdims(self) -> Tuple[int, int, int]:
+        return (self.cin, self.cout, self.k) if self.kind == "convt" else (self.cout, self.cin, self.k)
+
+    @property
+    def fwd_pack(self) -> int:
+        return L.PACK_CONVT_FWD if self.kind == "convt" else L.PACK_CONV_FWD
+
+    @property
+    def dgrad_pack(self) -> int:
+        if self.kind == "convt":
+            return L.PACK_CONVT_DGRAD
+        return L.PACK_CONV_DGRAD_S1 if self.stride == 1 else L.PACK_CONV_DGRAD_STRIDED
+
+
+def _fill(p: L.ConvParams, **kw) -> L.ConvParams:
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _new_params() -> L.ConvParams:
+    p = L.ConvParams()
+    p.nphase = 1
+    p.out_stride = 1
+    p.in_stride = 1
+    p.tap_step = 1
+    return p
+
+
+def fwd_params(g: ConvGeom, B: int, lin: int) -> L.ConvParams:
+    p = _new_params()
+    lout = g.out_len(lin)
+    if g.kind == "conv":
+        _fill(p, B=B, Lin=lin, Cin=g.cin, M=g.cout, Lout=lout, LoutTot=lout, J=g.k, in_stride=g.stride,
+              tap_step=g.dilation, off0=-g.padding)
+    elif g.kind == "cconv":
+        _fill(p, B=B, Lin=lin, Cin=g.cin, M=g.cout, Lout=lout, LoutTot=lout, J=g.k, in_stride=1,
+              tap_step=g.dilation, off0=-(g.k - 1) * g.dilation, pad_mode=1)
+    else:
+        s = g.stride
+        if s > L.GA_MAX_PHASE:
+            raise ValueError("transposed-conv stride > 8 unsupported")
+        _fill(p, B=B, Lin=lin, Cin=g.cin, M=g.cout, Lout=lin, LoutTot=lout, J=2, in_stride=1, tap_step=1, off0=-1,
+              out_stride=s, nphase=s)
+    return p
+
+
+def dgrad_params(g: ConvGeom, B: int, lin: int) -> L.ConvParams:
+    """Forward-form problem computing dx [B, lin, cin] from the output gradient [B, lout, cout]."""
+    p = _new_params()
+    lout = g.out_len(lin)
+    if g.kind == "conv" and g.stride == 1:
+        _fill(p, B=B, Lin=lout, Cin=g.cout, M=g.cin, Lout=lin, LoutTot=lin, J=g.k, tap_step=g.dilation,
+              off0=g.padding - (g.k - 1) * g.dilation)
+    elif g.kind == "conv":
+        if g.dilation != 1:
+            raise ValueError("strided conv with dilation unsupported")
+        s = g.stride
+        if s > L.GA_MAX_PHASE:
+            raise ValueError("conv stride > 8 unsupported")
+        jmax = (g.k + s - 1) // s
+        _fill(p, B=B, Lin=lout, Cin=g.cout, M=g.cin, Lout=(lin + s - 1) // s, LoutTot=lin, J=jmax, off0=-(jmax - 1),
+              out_stride=s, nphase=s)
+        for r in range(s):
+            p.phase_off0[r] = (r + g.padding) // s
+    elif g.kind == "cconv":
+        _fill(p, B=B, Lin=lout, Cin=g.cout, M=g.cin, Lout=lin, LoutTot=lin, J=g.k, tap_step=g.dilation, off0=0)
+    else:
+        _fill(p, B=B, Lin=lout, Cin=g.cout, M=g.cin, Lout=lin, LoutTot=lin, J=g.k, in_stride=g.stride, off0=0)
+    return p
+
+
+def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, res=None, dact_src=None, impl=L.IMPL_AUTO):
+    L.require_cuda(x, w, y)
+    assert x.is_contiguous() and w.is_contiguous() and y.is_contiguous()
+    assert x.dtype == w.dtype == y.dtype, (x.dtype, w.dtype, y.dtype)
+    assert x.numel() == p.B * p.Lin * p.Cin, (x.shape, p.B, p.Lin, p.Cin)
+    assert y.numel() == p.B * p.LoutTot * p.M, (y.shape, p.B, p.LoutTot, p.M)
+    assert w.numel() >= p.nphase * p.M * p.J * p.Cin
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == p.M
+    for t in (res, dact_src):
+        if t is not None:
+            assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
+    p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
+    L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
+
+
+_IMPL = L.IMPL_AUTO
+
+
+def set_conv_impl(impl: int) -> None:
+    """Force the convolution implementation (tests use this to cross-check MFMA against direct)."""
+    global _IMPL
+    _IMPL = impl
+
+
+def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None) -> Tensor:
+    B, lin, cin = x.shape
+    assert cin == g.cin, (cin, g.cin)
+    p = fwd_params(g, B, lin)
+    p.pre_act, p.post_act = pre_act, post_act
+    y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=x.dtype)
+    _launch_conv(p, x, wp, y, bias=bias, res=res, impl=_IMPL)
+    return y
+
+
+def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dact_src=None, res=None) -> Tensor:
+    B = gy.shape[0]
+    p = dgrad_params(g, B, lin)
+    p.dact_mode = dact_mode
+    dx = torch.empty((B, lin, g.cin), device=gy.device, dtype=gy.dtype)
+    _launch_conv(p, gy, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL)
+    if g.kind == "cconv" and g.k > 1:
+        # fold the gradient of the reflected left pad back: dx[l] += dxp[-l], l = 1..P   (in_stride = -1)
+        P = min((g.k - 1) * g.dilation, lin - 1)
+        if P > 0:
+            q = _new_params()
+            _fill(q, B=B, Lin=gy.shape[1], Cin=g.cout, M=g.cin, Lout=P, LoutTot=lin, J=g.k, in_stride=-1,
+                  tap_step=g.dilation, off0=0, t0=1, accumulate=1, dact_mode=dact_mode)
+            _launch_conv(q, gy, wp_d, dx, dact_src=dact_src, impl=L.IMPL_DIRECT)
+    return dx
+
+
+def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor) -> Tensor:
+    """Packed-forward-layout weight gradient [cout, k, cin] (fp32) of a 'conv' layer."""
+    assert g.kind == "conv"
+    L.require_cuda(ga, x)
+    assert ga.is_contiguous() and x.is_contiguous() and ga.dtype == x.dtype
+    B, lout, cout = ga.shape
+    p = L.WgradParams()
+    dw = torch.zeros((g.cout, g.k, g.cin), device=x.device, dtype=torch.float32)
+    _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout, Lout=lout, J=g.k,
+          in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
+    L.check(L.lib().ga_wgrad(C.byref(p), L.dt(x), _IMPL, L.stream()), "ga_wgrad")
+    return dw
+
+
+# ================================================================================================
+# weight packing (+ fused weight norm)
+def pack_weight(g: ConvGeom, w: Tensor, mode: int, dtype: torch.dtype, scale: Optional[Tensor] = None) -> Tensor:
+    L.require_cuda(w)
+    d0, d1, k = g.wdims
+    assert tuple(w.shape) == (d0, d1, k) and w.dtype == torch.float32 and w.is_contiguous()
+    n = L.lib().ga_packed_elems(mode, d0, d1, k, g.stride)
+    out = torch.empty((n,), device=w.device, dtype=dtype)
+    L.check(L.lib().ga_pack_weights(w.data_ptr(), L.ptr(scale), out.data_ptr(), L.dt(out), mode, d0, d1, k, g.stride,
+                                    g.padding, L.stream()), "ga_pack_weights")
+    return out
+
+
+def wn_scale(v: Tensor, gparam: Tensor) -> Tuple[Tensor, Tensor]:
+    rows = v.shape[0]
+    n = v.numel() // rows
+    scale = torch.empty((rows,), device=v.device, dtype=torch.float32)
+    norm = torch.empty_like(scale)
+    L.check(L.lib().ga_wn_scale(v.data_ptr(), gparam.data_ptr(), rows, n, scale.data_ptr(), norm.data_ptr(), L.stream()),
+            "ga_wn_scale")
+    return scale, norm
+
+
+class PackTrainable(torch.autograd.Function):
+    """(v, g | None) -> (forward pack, data-gradient pack) in the activation dtype.  Backward takes the
+    packed-forward-layout gradient from the weight-gradient kernel back to the parameter layout and through
+    the weight-norm (w = g*v/||v||, lab3_codec_models.py:125,143)."""
+
+    @staticmethod
+    def forward(ctx, v, gparam, geom: ConvGeom, dtype):
+        v = v.contiguous()
+        scale = norm = None
+        if gparam is not None:
+            scale, norm = wn_scale(v, gparam.contiguous())
+        wp_f = pack_weight(geom, v, geom.fwd_pack, dtype, scale)
+        wp_d = pack_weight(geom, v, geom.dgrad_pack, dtype, scale)
+        ctx.geom = geom
+        ctx.has_g = gparam is not None
+        ctx.save_for_backward(v, gparam, norm)
+        ctx.mark_non_differentiable(wp_f, wp_d)
+        # fp32 gradient carrier: autograd casts a gradient to the dtype of the tensor it belongs to, so the
+        # fp32 weight gradient cannot travel on the (possibly bf16) packed weights themselves.
+        carrier = torch.zeros((1,), device=v.device, dtype=torch.float32).expand(wp_f.numel())
+        return wp_f, wp_d, carrier
+
+    @staticmethod
+    def backward(ctx, _gwp_f, _gwp_d, gwp_f):
+        v, gparam, norm = ctx.saved_tensors
+        geom = ctx.geom
+        d0, d1, k = geom.wdims
+        if gwp_f is None:
+            return None, None, None, None
+        dw = torch.empty_like(v)
+        L.check(L.lib().ga_unpack_grad(gwp_f.contiguous().data_ptr(), dw.data_ptr(), geom.fwd_pack, d0, d1, k, geom.stride,
+                                       geom.padding, 0, L.stream()), "ga_unpack_grad")
+        if not ctx.has_g:
+            return dw, None, None, None
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(gparam)
+        L.check(L.lib().ga_wn_bwd(dw.data_ptr(), v.data_ptr(), gparam.contiguous().data_ptr(), norm.data_ptr(), d0, d1 * k,
+                                  dv.data_ptr(), dg.data_ptr(), 0, L.stream()), "ga_wn_bwd")
+        return dv, dg, None, None
+
+
+def pack_frozen(geom: ConvGeom, v: Tensor, gparam: Optional[Tensor], dtype) -> Tuple[Tensor, Tensor]:
+    with torch.no_grad():
+        scale = None
+        if gparam is not None:
+            scale, _ = wn_scale(v.contiguous(), gparam.contiguous())
+        return (pack_weight(geom, v.contiguous(), geom.fwd_pack, dtype, scale),
+                pack_weight(geom, v.contiguous(), geom.dgrad_pack, dtype, scale))
+
+
+# ================================================================================================
+def act_bwd(gy: Tensor, src: Tensor, mode: int) -> Tensor:
+    ga = torch.empty_like(gy)
+    L.check(L.lib().ga_act_bwd(gy.data_ptr(), src.data_ptr(), ga.data_ptr(), L.dt(gy), gy.numel(), mode, L.stream()), "ga_act_bwd")
+    return ga
+
+
+def colsum(g: Tensor) -> Tensor:
+    M = g.shape[-1]
+    out = torch.zeros((M,), device=g.device, dtype=torch.float32)
+    L.check(L.lib().ga_colsum(g.data_ptr(), L.dt(g), g.numel() // M, M, out.data_ptr(), L.stream()), "ga_colsum")
+    return out
+
+
+class ConvTrain(torch.autograd.Function):
+    """y = act(conv(x, w) + bias) for a trainable zero-padded Conv1d (G and D layers).
+    wp_f / wp_d come from PackTrainable; the weight gradient is returned in wp_f's packed layout."""
+
+    @staticmethod
+    def forward(ctx, x, wp_f, wp_d, carrier, bias, geom: ConvGeom, post_act: int):
+        x = x.contiguous()
+        y = conv_forward(geom, x, wp_f, bias, post_act=post_act)
+        ctx.geom, ctx.post_act = geom, post_act
+        ctx.save_for_backward(x, wp_d, y if post_act else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp_d, y = ctx.saved_tensors
+        geom = ctx.geom
+        gy = gy.contiguous()
+        ga = act_bwd(gy, y, L.DACT_LRELU_FROM_OUT) if ctx.post_act == L.ACT_LRELU else gy
+        if ctx.post_act not in (L.ACT_NONE, L.ACT_LRELU):
+            raise NotImplementedError("ConvTrain supports LeakyReLU or no activation")
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = conv_dgrad(geom, ga, wp_d, x.shape[1])
+        if ctx.needs_input_grad[3]:
+            gw = conv_wgrad(geom, ga, x).reshape(-1)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            gb = colsum(ga)
+        return gx, None, None, gw, gb, None, None
+
+
+class ConvFrozen(torch.autograd.Function):
+    """y = conv(pre_act(x)) + bias (+ res) with frozen weights (SEANet decoder): only dx is produced.
+    dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
+
+    @staticmethod
+    def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int):
+        x = x.contiguous()
+        y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous())
+        ctx.geom, ctx.pre_act = geom, pre_act
+        ctx.save_for_backward(x if pre_act else None, wp_d)
+        ctx.lin = x.shape[1]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp_d = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.pre_act == L.ACT_ELU:
+                gx = conv_dgrad(ctx.geom, gy, wp_d, ctx.lin, dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
+            elif ctx.pre_act == L.ACT_NONE:
+                gx = conv_dgrad(ctx.geom, gy, wp_d, ctx.lin)
+            else:
+                raise NotImplementedError
+        gres = gy if ctx.needs_input_grad[1] else None
+        return gx, gres, None, None, None, None, None
+
+
+# ================================================================================================
+class GnFilmAct(torch.autograd.Function):
+    """GroupNorm(G) -> FiLM (x*(1+a)+b) -> act (+ residual): lab3_codec_models.py:20-25,38-47,114-115."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ab, res, groups: int, act: int, eps: float):
+        x = x.contiguous()
+        B, T, Cn = x.shape
+        mean = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib = L.lib()
+        L.check(lib.ga_gn_stats(x.data_ptr(), L.dt(x), B, T, Cn, groups, eps, mean.data_ptr(), rstd.data_ptr(), L.stream()), "ga_gn_stats")
+        y = torch.empty_like(x)
+        if ab is not None:
+            ab = ab.contiguous()
+            assert ab.dtype == torch.float32 and tuple(ab.shape) == (B, 2 * Cn)
+        if res is not None:
+            res = res.contiguous()
+        L.check(lib.ga_gn_film_act_fwd(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                       L.ptr(ab), L.ptr(res), y.data_ptr(), L.dt(x), B, T, Cn, groups, act, L.stream()),
+                "ga_gn_film_act_fwd")
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, ab)
+        ctx.groups, ctx.act, ctx.has_res = groups, act, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta, ab = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, T, Cn = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(beta)
+        dab = torch.zeros_like(ab) if ab is not None else None
+        L.check(L.lib().ga_gn_film_act_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                           beta.data_ptr(), L.ptr(ab), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                           L.ptr(dab), L.dt(x), B, T, Cn, ctx.groups, ctx.act, L.stream()), "ga_gn_film_act_bwd")
+        return dx, dgamma, dbeta, dab, (dy if ctx.has_res else None), None, None, None
+
+
+class TanhResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, q, rscale: float):
+        raw = raw.contiguous()
+        q = q.contiguous()
+        y = torch.empty_like(raw)
+        L.check(L.lib().ga_tanh_residual_fwd(raw.data_ptr(), q.data_ptr(), y.data_ptr(), L.dt(raw), raw.numel(), rscale, L.stream()),
+                "ga_tanh_residual_fwd")
+        ctx.save_for_backward(raw)
+        ctx.rscale = rscale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, = ctx.saved_tensors
+        dy = dy.contiguous()
+        draw = torch.empty_like(raw)
+        L.check(L.lib().ga_tanh_residual_bwd(dy.data_ptr(), raw.data_ptr(), draw.data_ptr(), L.dt(raw), raw.numel(), ctx.rscale,
+                                             L.stream()), "ga_tanh_residual_bwd")
+        return draw, (dy if ctx.needs_input_grad[1] else None), None
+
+
+class AvgPool4s2(torch.autograd.Function):
+    """nn.AvgPool1d(4, 2, 1) on [B, L] rows (lab3_codec_models.py:159)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, Ln = x.shape
+        Lo = (Ln + 2 - 4) // 2 + 1
+        y = torch.empty((B, Lo), device=x.device, dtype=x.dtype)
+        L.check(L.lib().ga_avgpool1d_fwd(x.data_ptr(), y.data_ptr(), L.dt(x), B, Ln, Lo, L.stream()), "ga_avgpool1d_fwd")
+        ctx.shape = (B, Ln, Lo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Ln, Lo = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((B, Ln), device=dy.device, dtype=dy.dtype)
+        L.check(L.lib().ga_avgpool1d_bwd(dy.data_ptr(), dx.data_ptr(), L.dt(dy), B, Ln, Lo, L.stream()), "ga_avgpool1d_bwd")
+        return dx
+
+
+# ================================================================================================
+def _flat_view(t: Tensor) -> Tuple[Tensor, bool]:
+    """(contiguous tensor holding t's elements, whether it is t.permute(0,2,1)): NLC buffers shown as [B,C,L]
+    views are reduced in memory order without a copy."""
+    if t.is_contiguous():
+        return t, False
+    if t.dim() == 3 and t.permute(0, 2, 1).is_contiguous():
+        return t.permute(0, 2, 1), True
+    return t.contiguous(), False
+
+
+class ReduceSum(torch.autograd.Function):
+    """sum_i f(a_i, b_i) as a 1-element fp32 tensor; gradient flows to `a` (and, for |a-b|, to `b` if it needs one)."""
+
+    @staticmethod
+    def forward(ctx, a, b, op: int):
+        L.require_cuda(a)
+        af, perm = _flat_view(a)
+        bf = None
+        if b is not None:
+            bf, perm_b = _flat_view(b)
+            if perm_b != perm:
+                bf = (b.permute(0, 2, 1) if perm else b).contiguous()
+            assert bf.shape == af.shape and bf.dtype == af.dtype, "operands must share shape and dtype"
+        out = torch.zeros((1,), device=a.device, dtype=torch.float32)
+        L.check(L.lib().ga_reduce(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), op, 1.0, out.data_ptr(), L.stream()), "ga_reduce")
+        ctx.save_for_backward(af, bf)
+        ctx.op = op
+        ctx.permuted = perm
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        af, bf = ctx.saved_tensors
+        ga = torch.empty_like(af)
+        gout = gout.contiguous().float()
+        L.check(L.lib().ga_reduce_grad(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), ctx.op, gout.data_ptr(), 1.0,
+                                       ga.data_ptr(), 0, L.stream()), "ga_reduce_grad")
+        if ctx.permuted:
+            ga = ga.permute(0, 2, 1)
+        gb = None
+        if bf is not None and ctx.needs_input_grad[1]:
+            if ctx.op != L.RED_ABSDIFF:
+                raise NotImplementedError("gradient w.r.t. the second operand exists for |a-b| only")
+            gb = ga.neg()
+        return ga, gb, None
+
+
+def reduce_sum(a: Tensor, b: Optional[Tensor], op: int) -> Tensor:
+    return ReduceSum.apply(a, b, op)[0]
+
+
+class LatentSums(torch.autograd.Function):
+    """[sum|d|, sum_t|d[t+1]-d[t]|, per-sample sum|d| ...] for d = q_hat - q_src on NLC tensors."""
+
+    @staticmethod
+    def forward(ctx, qh, qs):
+        qh = qh.contiguous()
+        qs = qs.contiguous()
+        assert qh.shape == qs.shape and qh.dtype == qs.dtype
+        B, T, Cn = qh.shape
+        out = torch.zeros((2 + B,), device=qh.device, dtype=torch.float32)
+        L.check(L.lib().ga_latent_loss_fwd(qh.data_ptr(), qs.data_ptr(), L.dt(qh), B, T, Cn, out.data_ptr(), L.stream()),
+                "ga_latent_loss_fwd")
+        ctx.save_for_backward(qh, qs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qh, qs = ctx.saved_tensors
+        B, T, Cn = qh.shape
+        gout = gout.contiguous().float()
+        dq = torch.empty_like(qh)
+        L.check(L.lib().ga_latent_loss_bwd(qh.data_ptr(), qs.data_ptr(), L.dt(qh), B, T, Cn, gout.data_ptr(), dq.data_ptr(),
+                                           L.stream()), "ga_latent_loss_bwd")
+        return dq, None
+
+
+# ================================================================================================
+# MR-STFT: windowed DFT basis as conv weights (cached per resolution / dtype / device)
+_BASIS_CACHE = {}
+
+
+def _dft_basis(n_fft: int, hop: int, win: int, dtype: torch.dtype, device, rep: int):
+    key = (n_fft, hop, win, dtype, str(device), rep)
+    if key in _BASIS_CACHE:
+        return _BASIS_CACHE[key]
+    if n_fft % hop:
+        raise ValueError(f"MR-STFT kernel needs hop | n_fft, got n_fft={n_fft} hop={hop}")
+    nb = n_fft // 2 + 1
+    M = (2 * nb + 31) // 32 * 32
+    J = n_fft // hop
+    n = torch.arange(win, dtype=torch.float64)
+    window = 0.5 - 0.5 * torch.cos(2.0 * math.pi * n / win)
+    if win < n_fft:
+        left = (n_fft - win) // 2
+        window = torch.nn.functional.pad(window, (left, n_fft - win - left))
+    k = torch.arange(n_fft, dtype=torch.float64)
+    f = torch.arange(nb, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.outer(f, k) / n_fft
+    basis = torch.zeros((M, n_fft), dtype=torch.float64)
+    basis[:nb] = torch.cos(ang) * window
+    basis[nb:2 * nb] = -torch.sin(ang) * window
+    bf = basis.reshape(M, J, hop)  # [m][j][c], k = j*hop + c
+    if rep == 1:
+        w_f = bf.to(torch.float32).to(dtype)
+    else:  # bf16 hi/lo split: x*b ~= xhi*bhi + xlo*bhi + xhi*blo  (channels = [hi | lo | hi] x [bhi | bhi | blo])
+        hi = bf.to(torch.float32).to(torch.bfloat16)
+        lo = (bf - hi.to(torch.float64)).to(torch.float32).to(torch.bfloat16)
+        w_f = torch.cat([hi, hi, lo], dim=2)
+    # data-gradient form (stride-1 conv): Wd[c][j'][m] = basis[m][J-1-j'][c]
+    w_d = bf.flip(1).permute(2, 1, 0).contiguous().to(torch.float32).to(dtype)
+    out = (w_f.contiguous().to(device), w_d.to(device), nb, M, J)
+    _BASIS_CACHE[key] = out
+    return out
+
+
+class StftSums(torch.autograd.Function):
+    """[sum (my-mx)^2, sum my^2, sum |log mx - log my|, n_bins_total] for one resolution; x, y: [B, S]."""
+
+    @staticmethod
+    def forward(ctx, x, y, n_fft: int, hop: int, win: int, split: bool):
+        L.require_cuda(x, y)
+        ctx.in_dtype = x.dtype
+        x = x.contiguous().float()  # the DFT GEMM runs in exact fp32 (direct kernel) in this version
+        y = y.contiguous().float()
+        B, S = x.shape
+        lib = L.lib()
+        dtype = x.dtype
+        rep = 3 if (split and dtype == torch.bfloat16) else 1
+        w_f, w_d, nb, M, J = _dft_basis(n_fft, hop, win, dtype, x.device, rep)
+        P = n_fft // 2
+        rows = (S + 2 * P + hop - 1) // hop
+        frames = 1 + S // hop
+        specs = []
+        for sig in (x, y):
+            xp = torch.empty((B, rows, hop * rep), device=x.device, dtype=dtype)
+            L.check(lib.ga_stft_pad(sig.data_ptr(), xp.data_ptr(), L.dt(sig), L.dt(xp), B, S, n_fft, hop, rows, rep, L.stream()), "ga_stft_pad")
+            p = _new_params()
+            _fill(p, B=B, Lin=rows, Cin=hop * rep, M=M, Lout=frames, LoutTot=frames, J=J, off0=0)
+            spec = torch.empty((B, frames, M), device=x.device, dtype=dtype)
+            _launch_conv(p, xp, w_f, spec, impl=_IMPL)
+            specs.append(spec)
+        out = torch.zeros((3,), device=x.device, dtype=torch.float32)
+        L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.dt(specs[0]), B * frames, nb, M, out.data_ptr(),
+                                     L.stream()), "ga_stft_loss_fwd")
+        ctx.save_for_backward(specs[0], specs[1], w_d)
+        ctx.cfg = (B, S, n_fft, hop, rows, frames, nb, M, J)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sx, sy, w_d = ctx.saved_tensors
+        B, S, n_fft, hop, rows, frames, nb, M, J = ctx.cfg
+        lib = L.lib()
+        gout = gout.contiguous().float()
+        dsx = torch.empty_like(sx)
+        L.check(lib.ga_stft_loss_bwd(sx.data_ptr(), sy.data_ptr(), L.dt(sx), B * frames, nb, M, gout.data_ptr(), dsx.data_ptr(),
+                                     L.stream()), "ga_stft_loss_bwd")
+        p = _new_params()
+        _fill(p, B=B, Lin=frames, Cin=M, M=hop, Lout=rows, LoutTot=rows, J=J, off0=-(J - 1))
+        dxp = torch.empty((B, rows, hop), device=sx.device, dtype=sx.dtype)
+        _launch_conv(p, dsx, w_d, dxp, impl=_IMPL)
+        dx = torch.empty((B, S), device=sx.device, dtype=sx.dtype)
+        L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.dt(dxp), L.dt(dx), B, S, n_fft, hop, rows, 0, L.stream()),
+                "ga_stft_unpad_bwd")
+        return dx.to(ctx.in_dtype), None, None, None, None, None

@@ -1,0 +1,191 @@
+/* gan_amd C ABI - the drop-in boundary of the MI355X-native lab3 codec-GAN training step.
+ *
+ * The reference (asajid2-cell/gan) is pure Python on torch ATen ops; it has no FFI of its own.  Each entry
+ * point below replaces one ATen call site of the hot path; the citation on
+ * each declaration names that call site (paths relative to /root/reference).  The Python host in
+ * gan_amd/ binds these symbols with ctypes (gan_amd/_lib.py) and mirrors the reference's module API
+ * (lab 3/src/lab3_codec_models.py, lab3_codec_train.py, lab3_codec_bridge.py::decode_embeddings).
+ *
+ * Conventions
+ *   - every pointer is a device pointer in HBM unless its name starts with h_; no torch types
+ *   - activations are channels-last "NLC": [B][L][C], C contiguous; dtype GA_DTYPE_F32 or GA_DTYPE_BF16
+ *   - parameters, gradients of parameters, statistics and loss sums are fp32
+ *   - every function enqueues on `stream`, returns an int status (GA_OK == 0), never throws, never
+ *     synchronises and never allocates: callers pass outputs and workspaces
+ *   - functions that accumulate with atomics say so; the caller zeroes those outputs first
+ */
+#ifndef GAN_AMD_H
+#define GAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
+
+#define GA_OK 0
+#define GA_ERR_ARG 1
+#define GA_ERR_LAUNCH 2
+#define GA_ERR_ALIGN 3
+
+#define GA_DTYPE_F32 0
+#define GA_DTYPE_BF16 1
+
+#define GA_ACT_NONE 0
+#define GA_ACT_LRELU 1 /* leaky_relu(0.2): lab3_codec_models.py:128 */
+#define GA_ACT_ELU 2   /* nn.ELU(): HF modeling_encodec.py:268,330,340 */
+#define GA_ACT_SILU 3  /* F.silu: lab3_codec_models.py:42,46,115 */
+#define GA_ACT_TANH 4
+
+#define GA_DACT_NONE 0
+#define GA_DACT_LRELU_FROM_OUT 1
+#define GA_DACT_ELU_FROM_IN 2
+
+#define GA_IMPL_AUTO 0   /* MFMA for bf16 when the shape fills tiles, else direct */
+#define GA_IMPL_DIRECT 1 /* vector-ALU fp32 FMA chains (exact fp32 mode, thin layers) */
+#define GA_IMPL_MFMA 2   /* bf16 MFMA implicit GEMM; error if the shape is unsupported */
+
+#define GA_MAX_PHASE 8
+
+/* Generalised 1-D convolution in NLC layout ("forward form").
+ *   y[b][t*out_stride + phase][m] = epi( sum_{j<J} sum_{c<Cin} w[phase][m][j][c] * pre(x[b][row(t,j)][c]) )
+ *   row(t,j) = t*in_stride + j*tap_step + off0 + phase_off0[phase],  t in [t0, t0+Lout)
+ *   rows < 0: zero (pad_mode 0) or reflected to -row (pad_mode 1); rows >= Lin: zero
+ *   epi(v) = ( act(v + bias[m]) * dact(dact_src) ) + res  (+ old y when accumulate)
+ * Instances: Conv1d forward, its data gradient, ConvTranspose1d forward (one phase per output
+ * residue) and its data gradient, and the DFT-basis GEMM of the STFT. */
+typedef struct ga_conv_params {
+    const void* x;        /* [B][Lin][Cin] */
+    const void* w;        /* [nphase][M][J][Cin], packed by ga_pack_weights, same dtype as x */
+    void* y;              /* [B][LoutTot][M] */
+    const float* bias;    /* [M] or NULL */
+    const void* res;      /* [B][LoutTot][M] or NULL */
+    const void* dact_src; /* [B][LoutTot][M] or NULL */
+    int B, Lin, Cin, M;
+    int Lout;    /* number of output steps t */
+    int LoutTot; /* rows per batch item of y / res / dact_src */
+    int J, in_stride, tap_step, off0;
+    int out_stride, t0;
+    int pad_mode, pre_act, post_act, dact_mode, accumulate;
+    int nphase;
+    int phase_off0[GA_MAX_PHASE];
+} ga_conv_params;
+
+/* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients
+ *   G   lab3_codec_models.py:31-32,75,86 (k3, dilation 1/2/4/8)
+ *   D   lab3_codec_models.py:125,136-143 (k15 s1, k41 s4 x4, k3) + leaky_relu :128
+ *   dec HF modeling_encodec.py:106 (EncodecConv1d, reflect causal pad :157-176), :193 (EncodecConvTranspose1d,
+ *       right trim :206-233), called through lab3_codec_bridge.py:143 */
+int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t stream);
+
+/* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
+ * fp32 atomics into dw (caller zeroes); dw is in the packed forward layout [M][J][Cin].
+ * replaces: the weight-gradient half of conv1d backward for G and D (autograd of the call sites above,
+ * reached from loss_d.backward() / loss_g.backward(), lab3_codec_train.py:445,588) */
+typedef struct ga_wgrad_params {
+    const void* g; /* [B][LgTot][M] */
+    const void* x; /* [B][Lin][Cin] */
+    float* dw;     /* [M][J][Cin] */
+    int B, Lin, Cin, M, Lout, J, in_stride, tap_step, off0;
+    int LgTot, g_stride, g_phase;
+    int rows_per_split; /* set by the library */
+} ga_wgrad_params;
+int ga_wgrad(const ga_wgrad_params* h_params, int dtype, int impl, ga_stream_t stream);
+
+/* weight norm (torch.nn.utils.weight_norm, dim=0: lab3_codec_models.py:125,143; parametrizations.weight_norm in the
+ * HF decoder, modeling_encodec.py:109-111,196-201): scale[r] = g[r]/||v[r,:]||, norm[r] = ||v[r,:]|| */
+int ga_wn_scale(const float* v, const float* g, int rows, int n, float* scale, float* norm, ga_stream_t stream);
+
+#define GA_PACK_CONV_FWD 0           /* src [Co][Ci][K] -> [Co][K][Ci] */
+#define GA_PACK_CONV_DGRAD_S1 1      /* src [Co][Ci][K] -> [Ci][K][Co], taps flipped (stride-1 data gradient) */
+#define GA_PACK_CONV_DGRAD_STRIDED 2 /* src [Co][Ci][K] -> [S][Ci][ceil(K/S)][Co], one phase per input residue */
+#define GA_PACK_CONVT_FWD 3          /* src [Ci][Co][2S] -> [S][Co][2][Ci], one phase per output residue */
+#define GA_PACK_CONVT_DGRAD 4        /* src [Ci][Co][K] -> [Ci][K][Co] */
+size_t ga_packed_elems(int mode, int D0, int D1, int K, int S);
+/* dst[pack(s0,s1,k)] = src[s0][s1][k] * scale[s0]  (scale NULL => 1); dst dtype f32 or bf16.
+ * This is where "w = g * v / ||v||" is applied (fused weight-norm), once per step per layer. */
+int ga_pack_weights(const float* src, const float* scale, void* dst, int dtype, int mode, int D0, int D1, int K, int S, int P,
+                    ga_stream_t stream);
+/* dw[s0][s1][k] (+)= packed[pack(s0,s1,k)] : brings a packed-layout gradient back to the parameter layout */
+int ga_unpack_grad(const float* packed, float* dw, int mode, int D0, int D1, int K, int S, int P, int accumulate,
+                   ga_stream_t stream);
+/* backward of w = g*v/||v|| given dw (parameter layout [rows][n]) -> dv, dg */
+int ga_wn_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows, int n, float* dv, float* dg,
+              int accumulate, ga_stream_t stream);
+
+/* GroupNorm(8) -> FiLM -> SiLU (+ residual): lab3_codec_models.py:20-25,33-47,85,114-115
+ *   y = act(((x-mean)*rstd*gamma+beta)*(1+a[b,c]) + bb[b,c]) + res;  ab = [B][2C] = (a | bb) or NULL (no FiLM) */
+int ga_gn_stats(const void* x, int dtype, int B, int T, int C, int G, float eps, float* mean, float* rstd, ga_stream_t stream);
+int ga_gn_film_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* ab, const void* res, void* y, int dtype, int B, int T, int C, int G, int act,
+                       ga_stream_t stream);
+/* dgamma, dbeta [C] and dab [B][2C] are accumulated with atomics (caller zeroes) */
+int ga_gn_film_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* ab, void* dx, float* dgamma, float* dbeta, float* dab, int dtype,
+                       int B, int T, int C, int G, int act, ga_stream_t stream);
+
+/* q_hat = q_src + residual_scale * tanh(raw): lab3_codec_models.py:119 */
+int ga_tanh_residual_fwd(const void* raw, const void* q, void* y, int dtype, size_t n, float rscale, ga_stream_t stream);
+int ga_tanh_residual_bwd(const void* dy, const void* raw, void* draw, int dtype, size_t n, float rscale, ga_stream_t stream);
+
+/* nn.AvgPool1d(4, 2, 1) on [B][L]: lab3_codec_models.py:159,166 */
+int ga_avgpool1d_fwd(const void* x, void* y, int dtype, int B, int L, int Lo, ga_stream_t stream);
+int ga_avgpool1d_bwd(const void* dy, void* dx, int dtype, int B, int L, int Lo, ga_stream_t stream);
+
+/* ga = gy * act'(src): backward of leaky_relu (lab3_codec_models.py:128) */
+int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, int mode, ga_stream_t stream);
+/* out[m] += sum_rows g[row][m]: bias gradient of conv1d (atomics; caller zeroes) */
+int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, ga_stream_t stream);
+
+/* loss reductions: out[0] += scale * sum f(a,b) (atomics; caller zeroes)
+ *   hinge_d_loss / hinge_g_loss lab3_codec_models.py:171-176, F.l1_loss in feature_matching_loss :185 */
+#define GA_RED_ABSDIFF 0
+#define GA_RED_RELU1M 1
+#define GA_RED_RELU1P 2
+#define GA_RED_SUM 3
+#define GA_RED_SQ 4
+int ga_reduce(const void* a, const void* b, int dtype, size_t n, int op, float scale, float* out, ga_stream_t stream);
+int ga_reduce_grad(const void* a, const void* b, int dtype, size_t n, int op, const float* coef, float scale, void* ga,
+                   int accumulate, ga_stream_t stream);
+
+/* latent L1, first-difference L1 and per-sample |delta| sums in one pass: lab3_codec_train.py:464-465,552
+ *   out[0] = sum|d|, out[1] = sum_t |d[t+1]-d[t]|, out[2+b] = sum over sample b of |d|, d = q_hat - q_src (atomics) */
+int ga_latent_loss_fwd(const void* qh, const void* qs, int dtype, int B, int T, int C, float* out, ga_stream_t stream);
+int ga_latent_loss_bwd(const void* qh, const void* qs, int dtype, int B, int T, int C, const float* gout, void* dqh,
+                       ga_stream_t stream);
+
+/* MR-STFT loss (lab3_codec_train.py:148-176).  The DFT itself is ga_conv on the framed signal with the
+ * windowed cos/sin basis as weights; these are the kernels either side of it.
+ *   ga_stft_pad:      x [B][S] -> xp [B][rows][width] row-major view of the reflect-padded (n_fft/2 each side) signal,
+ *                     zero tail; width = hop*rep, rep=1 plain, rep=3 writes (hi, lo, hi) bf16 split of fp32 x
+ *   ga_stft_loss_fwd: spec [B][F][2*nb] (re | im) of prediction and target -> out[0] += sum (my-mx)^2,
+ *                     out[1] += sum my^2, out[2] += sum |log mx - log my|, magnitudes clamped at 1e-8
+ *   ga_stft_loss_bwd: dspec_x = d/dspec_x of c[0]*out0 + c[2]*out2 (target side has no gradient)
+ *   ga_stft_unpad_bwd: folds the gradient of the padded signal back onto x */
+int ga_stft_pad(const void* x, void* xp, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows, int rep,
+                ga_stream_t stream);
+int ga_stft_loss_fwd(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec, float* out,
+                     ga_stream_t stream);
+int ga_stft_loss_bwd(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec,
+                     const float* coef, void* dspec_x, ga_stream_t stream);
+int ga_stft_unpad_bwd(const void* dxp, void* dx, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows,
+                      int accumulate, ga_stream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step (lab3_codec_train.py:302-311,446-448,589-591) over flat
+ * fp32 buffers: out[0] += sum g^2 (atomics); then p,m,v updated in one pass, clip coefficient
+ * min(1, max_norm/(sqrt(sqnorm[0])*grad_scale + 1e-6)) folded in; grad_scale = 1/world_size under data parallel. */
+int ga_grad_sqnorm(const float* g, size_t n, float* out, ga_stream_t stream);
+int ga_adamw_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float max_norm, float grad_scale, const float* sqnorm,
+                   int write_clipped_grad, ga_stream_t stream);
+
+/* library identification: returns the gfx target the code objects were built for ("gfx950") */
+const char* ga_build_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAN_AMD_H */

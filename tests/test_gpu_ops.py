@@ -1,0 +1,277 @@
+"""GPU: each HIP kernel family, called through the C ABI (gan_amd.ops -> ctypes), against stock torch CPU ops.
+
+fp32 mode (direct kernels): rtol 1e-4 (relative to the tensor's max), the north-star fp32 bound.
+bf16 mode (MFMA kernels): inputs/weights rounded to bf16, fp32 accumulate: 2e-2 of the tensor's max.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gan_amd import _lib as L
+from gan_amd import ops
+from gan_amd.ops import ConvGeom
+
+DEV = "cuda"
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2.5e-2}
+
+
+def close(got, want, tol, name=""):
+    got = got.detach().float().cpu().double()
+    want = want.detach().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-12)
+    err = (got - want).abs().max().item() / scale
+    assert err <= tol, f"{name}: max err / max|ref| = {err:.3e} > {tol}"
+
+
+def _ref_conv(g, x, w, b, pre_act, post_act):
+    if pre_act == L.ACT_ELU:
+        x = F.elu(x)
+    if g.kind == "conv":
+        y = F.conv1d(x, w, b, stride=g.stride, padding=g.padding, dilation=g.dilation)
+    elif g.kind == "cconv":
+        pad = (g.k - 1) * g.dilation
+        y = F.conv1d(F.pad(x, (pad, 0), mode="reflect") if pad else x, w, b, dilation=g.dilation)
+    else:
+        y = F.conv_transpose1d(x, w, b, stride=g.stride)
+        y = y[..., : y.shape[-1] - (g.k - g.stride)]
+    if post_act == L.ACT_LRELU:
+        y = F.leaky_relu(y, 0.2)
+    return y
+
+
+TRAIN_CASES = [
+    # (geom, L, weight_norm, post_act)
+    (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 75, False, L.ACT_NONE),        # G in_proj
+    (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 75, False, L.ACT_NONE),        # G dilated block conv
+    (ConvGeom("conv", 1, 32, 15, 1, 7, 1), 1000, True, L.ACT_LRELU),        # D block 0 (Cin = 1)
+    (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 1001, True, L.ACT_LRELU),      # D block 1, odd length
+    (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 702, True, L.ACT_LRELU),      # D block 2
+    (ConvGeom("conv", 128, 256, 41, 4, 20, 1), 375, True, L.ACT_LRELU),     # D block 3
+    (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 259, True, L.ACT_LRELU),     # D block 4
+    (ConvGeom("conv", 512, 1, 3, 1, 1, 1), 65, True, L.ACT_NONE),           # D logits conv (Cout = 1)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=lambda c: f"{c[0].cin}-{c[0].cout}-k{c[0].k}s{c[0].stride}d{c[0].dilation}")
+def test_trainable_conv_forward_and_all_gradients(case, dtype):
+    g, Ln, wn, act = case
+    B = 3
+    torch.manual_seed(1)
+    x = torch.randn(B, g.cin, Ln)
+    v = torch.randn(g.cout, g.cin, g.k) / (g.cin * g.k) ** 0.5
+    gp = (torch.rand(g.cout, 1, 1) + 0.5) if wn else None
+    b = torch.randn(g.cout) * 0.1
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, vr, br = x.clone().requires_grad_(True), v.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    gr = gp.clone().requires_grad_(True) if wn else None
+    w_eff = vr * (gr / vr.reshape(g.cout, -1).norm(dim=1).reshape(-1, 1, 1)) if wn else vr
+    if dtype == torch.bfloat16:  # the kernel sees bf16-rounded effective weights
+        w_eff = w_eff + (w_eff.detach().bfloat16().float() - w_eff.detach())
+    y_ref = _ref_conv(g, xr, w_eff, br, 0, act)
+    gy = torch.randn_like(y_ref)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    refs = torch.autograd.grad(y_ref, [xr, vr, br] + ([gr] if wn else []), gy)
+
+    xg = x.permute(0, 2, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    vg, bg = v.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    gg = gp.to(DEV).requires_grad_(True) if wn else None
+    wp_f, wp_d, carrier = ops.PackTrainable.apply(vg, gg, g, dtype)
+    y = ops.ConvTrain.apply(xg, wp_f, wp_d, carrier, bg, g, act)
+    tol = TOL[dtype]
+    close(y.permute(0, 2, 1), y_ref, tol, "forward")
+    grads = torch.autograd.grad(y, [xg, vg, bg] + ([gg] if wn else []), gy.permute(0, 2, 1).contiguous().to(DEV, dtype))
+    close(grads[0].permute(0, 2, 1), refs[0], tol, "dx")
+    close(grads[1], refs[1], tol * (4 if dtype == torch.bfloat16 else 1), "dv")
+    close(grads[2], refs[2], tol, "dbias")
+    if wn:
+        close(grads[3], refs[3], tol * (4 if dtype == torch.bfloat16 else 1), "dg")
+
+
+def test_mfma_path_is_taken_and_matches_direct():
+    """bf16: the MFMA kernel must accept the fat layers (no silent direct fallback) and agree with the direct kernel."""
+    torch.manual_seed(2)
+    for g, Ln in ((ConvGeom("conv", 64, 128, 41, 4, 20, 1), 2050), (ConvGeom("conv", 256, 256, 3, 1, 2, 2), 375),
+                  (ConvGeom("convt", 128, 64, 8, 4), 300), (ConvGeom("cconv", 128, 512, 7), 375)):
+        B = 2
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        d0, d1, k = g.wdims
+        w = (torch.randn(d0, d1, k, device=DEV) / (g.cin * g.k) ** 0.5)
+        bias = torch.randn(g.cout, device=DEV)
+        for mode, fn in (("fwd", None), ("dgrad", None)):
+            pack = g.fwd_pack if mode == "fwd" else g.dgrad_pack
+            wp = ops.pack_weight(g, w, pack, torch.bfloat16)
+            outs = []
+            for impl in (L.IMPL_MFMA, L.IMPL_DIRECT):
+                ops.set_conv_impl(impl)
+                try:
+                    if mode == "fwd":
+                        outs.append(ops.conv_forward(g, x, wp, bias, pre_act=L.ACT_ELU if g.kind != "conv" else 0))
+                    else:
+                        gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+                        torch.manual_seed(3)
+                        outs.append(ops.conv_dgrad(g, gy, wp, Ln))
+                finally:
+                    ops.set_conv_impl(L.IMPL_AUTO)
+            if mode == "fwd":
+                close(outs[0], outs[1].float().cpu(), 1.5e-2, f"{g} {mode}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("kind", ["cconv7", "cconv3", "cconv1", "convt8", "convt5", "convt2", "tail"])
+def test_frozen_decoder_layers(kind, dtype):
+    torch.manual_seed(4)
+    B = 2
+    geom, Ln = {"cconv7": (ConvGeom("cconv", 128, 512, 7), 40), "cconv3": (ConvGeom("cconv", 256, 128, 3), 333),
+                "cconv1": (ConvGeom("cconv", 64, 128, 1), 500), "convt8": (ConvGeom("convt", 512, 256, 16, 8), 40),
+                "convt5": (ConvGeom("convt", 256, 128, 10, 5), 70), "convt2": (ConvGeom("convt", 64, 32, 4, 2), 400),
+                "tail": (ConvGeom("cconv", 32, 1, 7), 900)}[kind]
+    d0, d1, k = geom.wdims
+    v = torch.randn(d0, d1, k)
+    gp = torch.rand(d0, 1, 1) + 0.5
+    bias = torch.randn(geom.cout) * 0.1
+    x = torch.randn(B, geom.cin, Ln)
+    res = torch.randn(B, geom.cout, geom.out_len(Ln))
+    if dtype == torch.bfloat16:
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+    w_eff = v * (gp / v.reshape(d0, -1).norm(dim=1).reshape(-1, 1, 1))
+    if dtype == torch.bfloat16:
+        w_eff = w_eff.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    y_ref = _ref_conv(geom, xr, w_eff, bias, L.ACT_ELU, 0) + res
+    gy = torch.randn_like(y_ref)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    gx_ref, = torch.autograd.grad(y_ref, xr, gy)
+    wp_f, wp_d = ops.pack_frozen(geom, v.to(DEV), gp.to(DEV), dtype)
+    xg = x.permute(0, 2, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    y = ops.ConvFrozen.apply(xg, res.permute(0, 2, 1).contiguous().to(DEV, dtype), wp_f, wp_d, bias.to(DEV), geom, L.ACT_ELU)
+    close(y.permute(0, 2, 1), y_ref, TOL[dtype], "forward")
+    gx, = torch.autograd.grad(y, xg, gy.permute(0, 2, 1).contiguous().to(DEV, dtype))
+    close(gx.permute(0, 2, 1), gx_ref, TOL[dtype], "dx")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("C,film,res", [(256, True, True), (256, False, False), (192, True, False)])
+def test_groupnorm_film_silu(C, film, res, dtype):
+    torch.manual_seed(5)
+    B, T = 3, 75
+    x = torch.randn(B, C, T) * 1.5 + 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    ab = torch.randn(B, 2 * C) * 0.3 if film else None
+    r = torch.randn(B, C, T) if res else None
+    if res and dtype == torch.bfloat16:
+        r = r.bfloat16().float()
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta)] + ([ab.clone().requires_grad_(True)] if film else [])
+    h = F.group_norm(leaves[0], 8, leaves[1], leaves[2])
+    if film:
+        h = h * (1 + leaves[3][:, :C].unsqueeze(-1)) + leaves[3][:, C:].unsqueeze(-1)
+    y_ref = F.silu(h) + (r if res else 0)
+    gy = torch.randn_like(y_ref)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    refs = torch.autograd.grad(y_ref, leaves, gy)
+    xg = x.permute(0, 2, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    gl = [gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)]
+    abg = ab.to(DEV).requires_grad_(True) if film else None
+    rg = r.permute(0, 2, 1).contiguous().to(DEV, dtype) if res else None
+    y = ops.GnFilmAct.apply(xg, gl[0], gl[1], abg, rg, 8, L.ACT_SILU, 1e-5)
+    tol = TOL[dtype]
+    close(y.permute(0, 2, 1), y_ref, tol, "fwd")
+    grads = torch.autograd.grad(y, [xg] + gl + ([abg] if film else []), gy.permute(0, 2, 1).contiguous().to(DEV, dtype))
+    close(grads[0].permute(0, 2, 1), refs[0], tol, "dx")
+    close(grads[1], refs[1], tol, "dgamma")
+    close(grads[2], refs[2], tol, "dbeta")
+    if film:
+        close(grads[3], refs[3], tol, "dab")
+
+
+def test_small_elementwise_and_reductions():
+    torch.manual_seed(6)
+    B, Cn, T = 3, 128, 40
+    raw, q = torch.randn(B, T, Cn), torch.randn(B, T, Cn)
+    rr = raw.clone().requires_grad_(True)
+    y_ref = q + 0.5 * torch.tanh(rr)
+    gy = torch.randn_like(y_ref)
+    g_ref, = torch.autograd.grad(y_ref, rr, gy)
+    rg = raw.to(DEV).requires_grad_(True)
+    y = ops.TanhResidual.apply(rg, q.to(DEV), 0.5)
+    close(y, y_ref, 1e-5, "tanh fwd")
+    close(torch.autograd.grad(y, rg, gy.to(DEV))[0], g_ref, 1e-5, "tanh bwd")
+    for Ln in (1000, 1001, 37):
+        x = torch.randn(B, Ln)
+        xr = x.clone().requires_grad_(True)
+        p_ref = F.avg_pool1d(xr.unsqueeze(1), 4, 2, 1).squeeze(1)
+        gp = torch.randn_like(p_ref)
+        gx_ref, = torch.autograd.grad(p_ref, xr, gp)
+        xg = x.to(DEV).requires_grad_(True)
+        p = ops.AvgPool4s2.apply(xg)
+        close(p, p_ref, 1e-6, "pool fwd")
+        close(torch.autograd.grad(p, xg, gp.to(DEV))[0], gx_ref, 1e-6, "pool bwd")
+    a, b = torch.randn(B, 33, 77), torch.randn(B, 33, 77)
+    for op, f in ((L.RED_ABSDIFF, lambda u, w: (u - w).abs().sum()), (L.RED_RELU1M, lambda u, w: F.relu(1 - u).sum()),
+                  (L.RED_RELU1P, lambda u, w: F.relu(1 + u).sum()), (L.RED_SUM, lambda u, w: u.sum())):
+        ar = a.clone().requires_grad_(True)
+        s_ref = f(ar, b)
+        ga_ref, = torch.autograd.grad(s_ref * 0.37, ar)
+        ag = a.to(DEV).requires_grad_(True)
+        s = ops.reduce_sum(ag, b.to(DEV) if op == L.RED_ABSDIFF else None, op)
+        assert float(s) == pytest.approx(float(s_ref), rel=1e-5)
+        close(torch.autograd.grad(s * 0.37, ag)[0], ga_ref, 1e-6, f"reduce grad {op}")
+    # permuted ([B,C,L] view of an NLC buffer) operands are reduced without a copy and get a permuted gradient
+    an = a.permute(0, 2, 1).contiguous().to(DEV).requires_grad_(True)
+    s = ops.reduce_sum(an.permute(0, 2, 1), b.permute(0, 2, 1).contiguous().to(DEV).permute(0, 2, 1), L.RED_ABSDIFF)
+    assert float(s) == pytest.approx(float((a - b).abs().sum()), rel=1e-5)
+    ar = a.clone().requires_grad_(True)
+    close(torch.autograd.grad(s, an)[0].permute(0, 2, 1), torch.autograd.grad((ar - b).abs().sum(), ar)[0], 1e-6, "perm grad")
+
+
+def test_latent_losses_match_reference_formulas():
+    from gan_amd.lab3_codec_train import latent_losses
+    torch.manual_seed(7)
+    B, Cn, T = 3, 128, 30
+    qh, qs = torch.randn(B, Cn, T), torch.randn(B, Cn, T)
+    qr = qh.clone().requires_grad_(True)
+    l1 = F.l1_loss(qr, qs)
+    cont = F.l1_loss(qr[:, :, 1:] - qr[:, :, :-1], qs[:, :, 1:] - qs[:, :, :-1])
+    db = F.relu((qr - qs).abs().mean(dim=(1, 2)) - 0.75).mean()
+    g_ref, = torch.autograd.grad(4 * l1 + cont + 2 * db, qr)
+    qg = qh.to(DEV).requires_grad_(True)
+    a, b, c = latent_losses(qg, qs.to(DEV), 0.75)
+    assert float(a) == pytest.approx(float(l1), rel=1e-5) and float(b) == pytest.approx(float(cont), rel=1e-5)
+    assert float(c) == pytest.approx(float(db), rel=1e-5) and float(db) > 0
+    close(torch.autograd.grad(4 * a + b + 2 * c, qg)[0], g_ref, 1e-5, "latent grad")
+
+
+def test_fused_adamw_matches_torch_adamw_with_clipping():
+    from gan_amd.optim import FusedAdamW
+    torch.manual_seed(8)
+    shapes = [(33, 7, 3), (129,), (64, 64), (5,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    gp = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps]
+    opt_ref = torch.optim.AdamW(ref, lr=2e-4, betas=(0.5, 0.999))
+    opt = FusedAdamW(gp, lr=2e-4, betas=(0.5, 0.999), max_grad_norm=5.0)
+    for it in range(3):
+        grads = [torch.randn(s) * (10.0 if it == 1 else 0.1) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt_ref.step()
+        for p, g in zip(gp, grads):
+            p.grad = g.to(DEV)
+        opt.step()
+        assert float(opt.last_grad_norm) == pytest.approx(float(n_ref), rel=1e-5)
+        for a, b in zip(gp, ref):
+            close(a, b.detach(), 2e-6, f"adamw it{it}")
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    close(sd["state"][2]["exp_avg"], opt_ref.state_dict()["state"][2]["exp_avg"], 1e-5, "exp_avg")
