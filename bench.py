@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the lab3 codec-track G+D training step on MI355X (BASELINE.json metric: train samples/s).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration of train_codec_stage's loop body (reference lab3_codec_train.py:404-591) on one
+synthetic batch of the full codec shape: d_step_period=1, no R1, loss terms {adv, FM, latent L1, continuity, MR-STFT,
+delta budget}, clip 5.0 + AdamW on both networks - SURVEY.md section 8(d)'s unit of work.  Inputs are resident in HBM
+before the timed region.  Weak scaling: every rank processes its own batch of `--batch` samples; gradients are
+all-reduced over RCCL (gan_amd/dp.py).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_NAMES = {0: "conv_direct_kernel", 1: "conv_fewout_kernel", 2: "conv_cin1_kernel",
+                3: "conv_mfma_kernel<1,4,32>", 4: "conv_mfma_kernel<2,2,64>"}
+
+
+def make_models(precision: str, device, seed: int):
+    from gan_amd.lab3_codec_bridge import FrozenEncodec
+    from gan_amd.lab3_codec_models import CodecLatentTranslator, MultiScaleWaveDiscriminator
+    torch.manual_seed(seed)
+    G = CodecLatentTranslator(precision=precision).to(device).train()
+    D = MultiScaleWaveDiscriminator(3, precision=precision).to(device).train()
+    codec = FrozenEncodec(decoder_state_dict=None, device=device, precision=precision)
+    return G, D, codec
+
+
+def make_batch(B: int, T: int, device, gen: torch.Generator):
+    import torch.nn.functional as F
+    r = lambda *s: torch.randn(*s, generator=gen)
+    q_src = 0.5 * r(B, 128, T)
+    zc = F.normalize(r(B, 128), dim=-1)
+    zs = F.normalize(r(B, 128), dim=-1)
+    noise = r(B, 32)
+    bank = 0.5 * r(4 * 64, 128, T)  # 4 genres x 64 exemplars
+    idx_d = torch.randint(0, bank.shape[0], (B,), generator=gen)
+    idx_g = torch.randint(0, bank.shape[0], (B,), generator=gen)
+    return [t.to(device) for t in (q_src, zc, zs, noise, bank[idx_d], bank[idx_g])]
+
+
+def cpu_baseline(T: int, sample_B: int, iters: int):
+    """The CPU oracle (oracle/codec_oracle.py, a torch-CPU port of the reference step) timed on the host cores."""
+    from oracle import codec_oracle as O
+    n_threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(n_threads)
+    g_sd, d_sd, dec_sd = O.fresh_state()
+    gen = torch.Generator().manual_seed(328)
+    cfg = O.StepCfg(weights=O.Weights(content=0.0, style=0.0))
+    og, od = O.AdamWState(), O.AdamWState()
+    batch = [t.cpu() for t in make_batch(sample_B, T, "cpu", gen)]
+    O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 1, cfg)  # warm-up
+    t0 = time.perf_counter()
+    for i in range(iters):
+        O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 2 + i, cfg)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(sample_B / dt, 4), "unit": "samples/s", "cores": n_threads, "kind": "port",
+            "sample": f"{iters} iterations of the same step at B={sample_B}, T={T} (S={T*320}), fp32, after 1 warm-up; "
+                      f"{dt:.2f} s/iteration"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="samples per GPU (reference default batch size, run_lab3_codec.py:201)")
+    ap.add_argument("--frames", type=int, default=375, help="latent frames T (5 s x 75 Hz); S = 320*T samples")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from gan_amd.dp import DataParallel
+        dp = DataParallel()
+
+    from gan_amd import ops
+    from gan_amd.lab3_codec_models import CodecTrainWeights
+    from gan_amd.lab3_codec_train import CodecStageTrainConfig, codec_train_iteration
+    from gan_amd.optim import FusedAdamW
+
+    G, D, codec = make_models(args.precision, device, seed=328)
+    scfg = CodecStageTrainConfig(stage_name="stage2", epochs=1, d_step_period=1, r1_gamma=0.0, g_grad_clip_norm=5.0,
+                                 d_grad_clip_norm=5.0, weights=CodecTrainWeights(content=0.0, style=0.0))
+    opt_g = FusedAdamW(G.parameters(), lr=scfg.lr_g, betas=scfg.betas)
+    opt_d = FusedAdamW(D.parameters(), lr=scfg.lr_d, betas=scfg.betas)
+    if dp is not None:
+        dp.broadcast_params(opt_g, opt_d)
+    gen = torch.Generator().manual_seed(328 + rank)
+    batches = [make_batch(args.batch, args.frames, device, gen) for _ in range(2)]
+
+    def step(i):
+        b = batches[i % len(batches)]
+        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
+
+    def barrier():
+        if dp is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dp is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_g = float(out["loss_g"])
+    assert loss_g == loss_g, "loss is NaN"
+
+    # per-kernel accounting: one more step with HIP events (torch current stream == launch stream) around every
+    # convolution launch; achieved = launched multiply-add flops / event time, per kernel.
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ops.PROFILE = []
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        for kid, flops, e0, e1 in prof:
+            k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            k["launches"] += 1
+            k["flops"] += flops
+            k["ms"] += e0.elapsed_time(e1)
+        dom = max((k for k in kernels if k >= 3), key=lambda k: kernels[k]["ms"], default=None)
+        if dom is not None:
+            k = kernels[dom]
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
+                        "flops_per_launch_avg": k["flops"] / k["launches"]}
+
+    if rank == 0:
+        total_samples = args.batch * world * args.steps
+        line = {
+            "metric": "G+D train samples/sec", "value": round(total_samples / elapsed, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "lab3 codec GAN full-size codec shape (T=%d latent frames, S=%d samples), G 256ch x10 "
+                                   "blocks, 3-scale D, frozen SEANet decoder; d_step_period=1, no R1, losses adv+FM+latent+"
+                                   "continuity+MR-STFT, clip 5 + AdamW" % (args.frames, args.frames * 320),
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "random_init_weights": True},
+            "roofline": roofline,
+            "kernel_breakdown": {KERNEL_NAMES[k]: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                                    "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+                                 for k, v in sorted(kernels.items())},
+            "loss_g_last": round(loss_g, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_sample_batch, args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    if dp is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

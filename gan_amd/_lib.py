@@ -47,6 +47,7 @@ class WgradParams(C.Structure):
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
+    "ga_conv_kernel_id": [C.POINTER(ConvParams), _I, _I],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -128,10 +128,20 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
+    if PROFILE is None:
+        L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
+        return
+    # benchmark accounting: HIP events on the launch stream around this one launch + its multiply-adds as launched
+    kid = L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
+    e1.record()
+    PROFILE.append((kid, 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin, e0, e1))
 
 
 _IMPL = L.IMPL_AUTO
+PROFILE = None  # set to a list by bench.py to collect (kernel id, launched flops, start event, end event)
 
 
 def set_conv_impl(impl: int) -> None:

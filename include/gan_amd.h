@@ -81,6 +81,14 @@ typedef struct ga_conv_params {
  *       right trim :206-233), called through lab3_codec_bridge.py:143 */
 int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t stream);
 
+/* which kernel ga_conv would launch for these parameters (for tests and the benchmark's per-kernel accounting) */
+#define GA_KERNEL_DIRECT_TILE 0
+#define GA_KERNEL_DIRECT_FEWOUT 1
+#define GA_KERNEL_DIRECT_CIN1 2
+#define GA_KERNEL_MFMA_64x128 3  /* conv_mfma_kernel<1,4,32> */
+#define GA_KERNEL_MFMA_128x128 4 /* conv_mfma_kernel<2,2,64> */
+int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
+
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
  * fp32 atomics into dw (caller zeroes); dw is in the packed forward layout [M][J][Cin].
  * replaces: the weight-gradient half of conv1d backward for G and D (autograd of the call sites above,
