@@ -31,8 +31,8 @@ def assert_summary_close(got: torch.Tensor, want: np.ndarray, rtol=1e-4, name=""
     g = tsummary(got)
     scale = max(want[2], 1e-12)
     n = max(1, got.numel())
-    assert abs(g[0] - want[0]) <= rtol * max(want[0], 1e-12), f"{name}: norm {g[0]} vs {want[0]}"
-    assert abs(g[2] - want[2]) <= rtol * scale, f"{name}: abssum {g[2]} vs {want[2]}"
+    assert abs(g[0] - want[0]) <= rtol * max(want[0], 1e-12) + sum_atol, f"{name}: norm {g[0]} vs {want[0]}"
+    assert abs(g[2] - want[2]) <= rtol * scale + sum_atol, f"{name}: abssum {g[2]} vs {want[2]}"
     assert abs(g[1] - want[1]) <= rtol * scale + sum_atol, f"{name}: sum {g[1]} vs {want[1]}"
     elem = scale / n  # mean |x|
     np.testing.assert_allclose(g[3:], want[3:], rtol=rtol * 10, atol=(rtol * 10 * elem if elem_atol is None else elem_atol), err_msg=name)
