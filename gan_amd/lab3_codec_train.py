@@ -217,14 +217,20 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
                       style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
     x_hat = codec.decode_embeddings(q_hat)
-    with torch.no_grad():
-        x_src = codec.decode_embeddings(q_src)
-
     take_d_step = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
+    # The reference decodes q_src, q_real_tgt and q_real_tgt_g in three separate no-grad calls (:415,422,458).  The
+    # decoder is frozen and acts on every batch item independently, so one batched call gives the same waveforms with a
+    # third of the (launch-bound) LSTM steps.
+    B0 = int(q_src.shape[0])
+    with torch.no_grad():
+        frozen_in = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
+        frozen_out = codec.decode_embeddings(torch.cat(frozen_in, dim=0))
+        x_src = frozen_out[:B0]
+        x_real_d_all = frozen_out[B0:2 * B0] if take_d_step else None
+        x_real_g = frozen_out[-B0:]
+
     if take_d_step:
-        with torch.no_grad():
-            x_real = codec.decode_embeddings(q_real_tgt)
-        x_real = x_real.detach().requires_grad_(float(stage_cfg.r1_gamma) > 0.0)
+        x_real = x_real_d_all.detach().requires_grad_(float(stage_cfg.r1_gamma) > 0.0)
         real_outs = discriminator(x_real)
         fake_outs_d = discriminator(x_hat.detach())
         loss_d = multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d)
@@ -248,9 +254,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         out["loss_d"] = loss_d_total
         out["d_grad_norm"] = opt_d.last_grad_norm
 
-    q_real = q_real_tgt_g
     with torch.no_grad():
-        x_real_g = codec.decode_embeddings(q_real)
         real_outs_g = discriminator(x_real_g)
     # D's own gradients from the G step are discarded by the reference (zero_grad(set_to_none) at :444 before they
     # are ever used), so the fake pass runs with D's parameters frozen: no D weight-gradient kernels are launched.

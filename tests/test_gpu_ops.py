@@ -123,6 +123,24 @@ def test_mfma_path_is_taken_and_matches_direct():
                 close(outs[0], outs[1].float().cpu(), 1.5e-2, f"{g} {mode}")
 
 
+def test_mfma_weight_gradient_matches_direct():
+    """bf16 weight gradient: transposed-LDS-read MFMA kernel against the direct kernel on the same bf16 operands."""
+    torch.manual_seed(9)
+    for g, Ln, B in ((ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 2), (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 1875, 2),
+                     (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 3), (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 375, 3),
+                     (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 938, 2)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        ga = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+        outs = []
+        for impl in (L.IMPL_MFMA, L.IMPL_DIRECT):
+            ops.set_conv_impl(impl)
+            try:
+                outs.append(ops.conv_wgrad(g, ga, x))
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
+        close(outs[0], outs[1].cpu(), 2e-3, f"wgrad {g}")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("kind", ["cconv7", "cconv3", "cconv1", "convt8", "convt5", "convt2", "tail"])
 def test_frozen_decoder_layers(kind, dtype):
