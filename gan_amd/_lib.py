@@ -37,7 +37,7 @@ class ConvParams(C.Structure):
 
 class WgradParams(C.Structure):
     _fields_ = [
-        ("g", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p),
+        ("g", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
         ("B", C.c_int), ("Lin", C.c_int), ("Cin", C.c_int), ("M", C.c_int), ("Lout", C.c_int), ("J", C.c_int),
         ("in_stride", C.c_int), ("tap_step", C.c_int), ("off0", C.c_int),
         ("LgTot", C.c_int), ("g_stride", C.c_int), ("g_phase", C.c_int), ("rows_per_split", C.c_int),

@@ -7,6 +7,11 @@ int ga_conv_mfma_supported(const ConvParams& p);
 int ga_conv_mfma_impl(const ConvParams& p, hipStream_t s);
 int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
+int ga_thin_conv_supported(const ConvParams& p, int dtype);
+int ga_thin_conv_impl(const ConvParams& p, int dtype, hipStream_t s);
+int ga_thin_wgrad_supported(const WgradParams& p, int dtype);
+int ga_thin_wgrad_impl(const WgradParams& p, float* dbias, int dtype, int kind, hipStream_t s);
+extern "C" int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s);
 
 extern "C" {
 
@@ -18,6 +23,10 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     if (impl == GA_IMPL_MFMA) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_AUTO && can_mfma && (long)p.Lout * p.B >= 64) return ga_conv_mfma_impl(p, s);
     if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) return GA_ERR_ARG;
+    if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) {
+        if (!p.x || !p.w || !p.y || p.nphase < 1 || p.nphase > GA_MAX_PHASE || (long)p.B * p.nphase > 65535) return GA_ERR_ARG;
+        return p.Lout > 0 ? ga_thin_conv_impl(p, dtype, s) : GA_OK;
+    }
     return ga_conv_direct_impl(p, dtype, s);
 }
 
@@ -27,6 +36,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool mfma = (impl == GA_IMPL_MFMA && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && (long)p.Lout * p.B >= 64);
     if (mfma) return p.M <= 64 ? GA_KERNEL_MFMA_64x128 : GA_KERNEL_MFMA_128x128;
+    if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) return p.M <= 4 ? GA_KERNEL_THIN_FEWOUT_ROWS : GA_KERNEL_THIN_CIN1_VEC;
     if (p.M <= 4) return GA_KERNEL_DIRECT_FEWOUT;
     if (p.Cin == 1 && p.nphase == 1) return GA_KERNEL_DIRECT_CIN1;
     return GA_KERNEL_DIRECT_TILE;
@@ -36,11 +46,22 @@ int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {
     if (!hp) return GA_ERR_ARG;
     if (dtype != GA_DTYPE_F32 && dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
     const WgradParams& p = *hp;
+    if (!p.g || !p.x || !p.dw || p.B <= 0 || p.Lin <= 0 || p.Cin <= 0 || p.M <= 0 || p.Lout < 0 || p.J <= 0) return GA_ERR_ARG;
+    if (p.g_stride < 1 || p.LgTot < 1 || p.B > 65535) return GA_ERR_ARG;
+    if (p.Lout == 0) return GA_OK;
+    const int thin = ga_thin_wgrad_supported(p, dtype);
+    if (thin && impl != GA_IMPL_MFMA) return ga_thin_wgrad_impl(p, p.dbias, dtype, thin, s);  // fuses the bias gradient
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_wgrad_mfma_supported(p);
-    if (impl == GA_IMPL_MFMA) return can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
-    if (impl == GA_IMPL_AUTO && can_mfma) return ga_wgrad_mfma_impl(p, s);
-    if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) return GA_ERR_ARG;
-    return ga_wgrad_direct_impl(p, dtype, s);
+    int rc;
+    if (impl == GA_IMPL_MFMA) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
+    else if (impl == GA_IMPL_AUTO && can_mfma) rc = ga_wgrad_mfma_impl(p, s);
+    else if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) rc = GA_ERR_ARG;
+    else rc = ga_wgrad_direct_impl(p, dtype, s);
+    if (rc == GA_OK && p.dbias) {
+        if (p.g_stride != 1 || p.g_phase != 0 || p.LgTot != p.Lout) return GA_ERR_ARG;
+        rc = ga_colsum(p.g, dtype, (size_t)p.B * p.Lout, p.M, p.dbias, s);
+    }
+    return rc;
 }
 
 const char* ga_build_target(void) { return "gfx950"; }

@@ -454,6 +454,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 
 // ================================================================================================
 // C ABI
+int ga_colsum_vec_supported(const void* g, int dtype, int M);
+int ga_colsum_vec_impl(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s);
 static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
     size_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -588,6 +590,8 @@ int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, i
 int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s) {
     if (!g || !out || M <= 0) return GA_ERR_ARG;
     if (rows == 0) return GA_OK;
+    if (dtype != GA_DTYPE_F32 && dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
+    if (ga_colsum_vec_supported(g, dtype, M)) return ga_colsum_vec_impl(g, dtype, rows, M, out, s);
     size_t blocks = (rows + 511) / 512;
     if (blocks > 1024) blocks = 1024;
     const size_t rpb = (rows + blocks - 1) / blocks;

@@ -1,0 +1,386 @@
+// HBM-bound kernels for the thin ends of the networks (one input channel or a single output channel), where a GEMM
+// view would leave MFMA tiles empty: D block 0 (1 -> 32, k15), D's logit conv (512 -> 1, k3), the decoder's last conv
+// (32 -> 1, k7) and their gradients.  Every thread moves 16-byte vectors of 8 channels; fp32 accumulation.
+#include "common.h"
+
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    float v[8];
+    typedef __attribute__((ext_vector_type(8))) __bf16 raw_t;
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const raw_t r = *(const raw_t*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        raw_t r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+        *(raw_t*)p = r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward form, M <= 4, one THREAD per output step: y[t][m] = sum_j sum_c w[m][j][c] * pre(x[row(t,j)][c]).
+// Weights (M*J*Cin floats) sit in LDS and are read as broadcasts; x rows are read as 16-byte vectors and overlap
+// between neighbouring threads (served by L1/L2).  Cin % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_fewout_rows_kernel(ConvParams p) {
+    extern __shared__ float wsm[];  // [M][J*Cin]
+    const T* __restrict__ x = (const T*)p.x;
+    const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+    const int KC = p.J * p.Cin;
+    const T* __restrict__ w = (const T*)p.w + (size_t)phase * p.M * KC;
+    for (int i = threadIdx.x; i < p.M * KC; i += blockDim.x) wsm[i] = (float)w[i];
+    __syncthreads();
+    const int off0 = p.off0 + p.phase_off0[phase];
+    x += (size_t)b * p.Lin * p.Cin;
+    for (int t = p.t0 + blockIdx.x * blockDim.x + threadIdx.x; t < p.t0 + p.Lout; t += gridDim.x * blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < p.J; ++j) {
+            int row = t * p.in_stride + j * p.tap_step + off0;
+            if (row < 0 && p.pad_mode == 1) row = -row;
+            if (row < 0 || row >= p.Lin) continue;
+            const T* xr = x + (size_t)row * p.Cin;
+            const float* wj = wsm + j * p.Cin;
+            for (int c = 0; c < p.Cin; c += 8) {
+                Vec8<T> xv;
+                xv.load(xr + c);
+                if (p.pre_act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv.v[e] = act_apply(p.pre_act, xv.v[e]);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (m < p.M) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[m] = fmaf(xv.v[e], wj[m * KC + c + e], acc[m]);
+                    }
+                }
+            }
+        }
+        const int orow = t * p.out_stride + phase;
+        if (orow < 0 || orow >= p.LoutTot) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m >= p.M) continue;
+            const size_t idx = ((size_t)b * p.LoutTot + orow) * p.M + m;
+            float v = acc[m];
+            if (p.bias) v += p.bias[m];
+            v = act_apply(p.post_act, v);
+            if (p.dact_mode) v *= dact_apply(p.dact_mode, (float)((const T*)p.dact_src)[idx]);
+            if (p.res) v += (float)((const T*)p.res)[idx];
+            if (p.accumulate) v += (float)((T*)p.y)[idx];
+            ((T*)p.y)[idx] = (T)v;
+        }
+    }
+}
+
+// forward form, Cin == 1, M % 8 == 0 (D block 0): thread = (output step, group of 8 output channels), 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin1_vec_kernel(ConvParams p) {
+    extern __shared__ float wsm[];  // [J][M] (transposed for contiguous 8-channel reads) + [M] bias
+    const T* __restrict__ x = (const T*)p.x + (size_t)blockIdx.z * p.Lin;
+    const T* __restrict__ w = (const T*)p.w;
+    for (int i = threadIdx.x; i < p.M * p.J; i += blockDim.x) wsm[(i % p.J) * p.M + i / p.J] = (float)w[i];
+    for (int i = threadIdx.x; i < p.M; i += blockDim.x) wsm[p.M * p.J + i] = p.bias ? p.bias[i] : 0.f;
+    __syncthreads();
+    const int parts = p.M / 8;
+    const size_t total = (size_t)p.Lout * parts;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int t = p.t0 + (int)(e / parts), m0 = (int)(e % parts) * 8;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = wsm[p.M * p.J + m0 + i];
+        for (int j = 0; j < p.J; ++j) {
+            int row = t * p.in_stride + j * p.tap_step + p.off0;
+            if (row < 0 && p.pad_mode == 1) row = -row;
+            if (row < 0 || row >= p.Lin) continue;
+            float xv = (float)x[row];
+            if (p.pre_act) xv = act_apply(p.pre_act, xv);
+            const float* wj = wsm + j * p.M + m0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wj[i], acc[i]);
+        }
+        const int orow = t * p.out_stride;
+        if (orow >= p.LoutTot) continue;
+        const size_t idx = ((size_t)blockIdx.z * p.LoutTot + orow) * p.M + m0;
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = act_apply(p.post_act, acc[i]);
+        if (p.dact_mode) {
+            Vec8<T> d;
+            d.load((const T*)p.dact_src + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] *= dact_apply(p.dact_mode, d.v[i]);
+        }
+        if (p.res) {
+            Vec8<T> d;
+            d.load((const T*)p.res + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] += d.v[i];
+        }
+        if (p.accumulate) {
+            Vec8<T> d;
+            d.load((T*)p.y + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] += d.v[i];
+        }
+        o.store((T*)p.y + idx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, Cin == 1, M % 8 == 0, J <= 16:  dw[m][j] += sum_{b,t} g[b][t][m] * x[b][t*S + j*step + off0]
+// and, fused, the bias gradient db[m] += sum g.  A block owns a run of consecutive steps of one batch item.
+#define WG1_ROWS 2048
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_cin1_kernel(WgradParams p, float* __restrict__ dbias, int chunks_per_b) {
+    __shared__ float xs[WG1_ROWS * 4 + 64];   // window for in_stride <= 4
+    __shared__ float red[256 * 17];
+    const T* __restrict__ g = (const T*)p.g;
+    const T* __restrict__ x = (const T*)p.x;
+    const int b = blockIdx.x / chunks_per_b;
+    const int t0 = (blockIdx.x % chunks_per_b) * WG1_ROWS;
+    int nrows = p.Lout - t0;
+    if (nrows > WG1_ROWS) nrows = WG1_ROWS;
+    const int span = (nrows - 1) * p.in_stride + (p.J - 1) * p.tap_step + 1;
+    const int R0 = t0 * p.in_stride + p.off0;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int R = R0 + i;
+        xs[i] = (R >= 0 && R < p.Lin) ? (float)x[(size_t)b * p.Lin + R] : 0.f;
+    }
+    __syncthreads();
+    const int parts = p.M / 8;            // threads per row
+    const int lanes = 256 / parts;        // rows in flight
+    const int part = threadIdx.x % parts, rl = threadIdx.x / parts;
+    float acc[8][16];
+    float accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        accb[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    }
+    if (rl < lanes) {
+        for (int r = rl; r < nrows; r += lanes) {
+            Vec8<T> gv;
+            gv.load(g + ((size_t)b * p.LgTot + (size_t)(t0 + r) * p.g_stride + p.g_phase) * p.M + part * 8);
+            const float* xw = xs + r * p.in_stride;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < p.J) {
+                    const float xv = xw[j * p.tap_step];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i][j] = fmaf(gv.v[i], xv, acc[i][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accb[i] += gv.v[i];
+        }
+    }
+    // reduce over the row lanes: 17 values (16 taps + bias) per (part, channel)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[threadIdx.x * 17 + j] = acc[i][j];
+        red[threadIdx.x * 17 + 16] = accb[i];
+        __syncthreads();
+        // thread (part', j) sums over row lanes
+        for (int o = threadIdx.x; o < parts * 17; o += blockDim.x) {
+            const int pt = o / 17, j = o % 17;
+            float s = 0.f;
+            for (int l = 0; l < lanes; ++l) s += red[(l * parts + pt) * 17 + j];
+            const int m = pt * 8 + i;
+            if (j < p.J) atomicAdd(&p.dw[(size_t)m * p.J + j], s);
+            else if (j == 16 && dbias) atomicAdd(&dbias[m], s);
+        }
+    }
+}
+
+// weight gradient, M == 1, Cin % 8 == 0, J <= 8: dw[j][c] += sum_{b,t} g[b][t] * x[b][t*S + j*step + off0][c]; db += sum g.
+// Each thread owns 8 channels and walks a run of INPUT rows once, scattering each row into the taps that use it.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_m1_kernel(WgradParams p, float* __restrict__ dbias, int rows_per_block) {
+    __shared__ float red[16];
+    const T* __restrict__ g = (const T*)p.g;
+    const T* __restrict__ x = (const T*)p.x;
+    const int parts = p.Cin / 8;
+    const int lanes = 256 / parts;
+    const int part = threadIdx.x % parts, rl = threadIdx.x / parts;
+    const int b = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block;
+    int r_end = r_begin + rows_per_block;
+    if (r_end > p.Lin) r_end = p.Lin;
+    float acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    if (rl < lanes) {
+        for (int R = r_begin + rl; R < r_end; R += lanes) {
+            Vec8<T> xv;
+            xv.load(x + ((size_t)b * p.Lin + R) * p.Cin + part * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < p.J) {
+                    const int num = R - j * p.tap_step - p.off0;   // t * S
+                    if (num >= 0 && num % p.in_stride == 0) {
+                        const int t = num / p.in_stride;
+                        if (t < p.Lout) {
+                            const float gv = (float)g[(size_t)b * p.LgTot + (size_t)t * p.g_stride + p.g_phase];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(gv, xv.v[i], acc[j][i]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < p.J)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) atomicAdd(&p.dw[(size_t)j * p.Cin + part * 8 + i], acc[j][i]);
+    }
+    if (dbias && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int t = threadIdx.x; t < p.Lout; t += blockDim.x) s += (float)g[(size_t)b * p.LgTot + (size_t)t * p.g_stride + p.g_phase];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) atomicAdd(dbias, s);
+    }
+}
+
+// column sums with 16-byte loads: out[m] += sum_rows g[row][m], M % 8 == 0, M <= 2048
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ g, size_t rows, int M, float* __restrict__ out,
+                                                          size_t rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int parts = M / 8;
+    const int lanes = 256 / parts > 0 ? 256 / parts : 1;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    size_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int pbase = 0; pbase < parts; pbase += 256) {
+        const int part = pbase + (threadIdx.x % (parts < 256 ? parts : 256));
+        const int rl = parts < 256 ? threadIdx.x / parts : 0;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rl < lanes && part < parts) {
+            for (size_t r = r0 + rl; r < r1; r += lanes) {
+                Vec8<T> v;
+                v.load(g + r * M + part * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += v.v[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+        __syncthreads();
+        const int np = parts < 256 ? parts : 256;
+        for (int o = threadIdx.x; o < np * 8; o += blockDim.x) {
+            const int pt = o / 8, i = o % 8;
+            float s = 0.f;
+            if (parts < 256) {
+                for (int l = 0; l < lanes; ++l) s += red[(l * parts + pt) * 8 + i];
+            } else {
+                s = red[pt * 8 + i];
+            }
+            if (pbase + pt < parts) atomicAdd(&out[(pbase + pt) * 8 + i], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename T>
+static int thin_conv_t(const ConvParams& p, hipStream_t s) {
+    if (p.M <= 4) {
+        int gx = (p.Lout + 255) / 256;
+        if (gx > 16384) gx = 16384;
+        conv_fewout_rows_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, (size_t)p.M * p.J * p.Cin * sizeof(float), s>>>(p);
+    } else {
+        const size_t total = (size_t)p.Lout * (p.M / 8);
+        size_t gx = (total + 255) / 256;
+        if (gx > 8192) gx = 8192;
+        conv_cin1_vec_kernel<T><<<dim3((unsigned)gx, 1, p.B), 256, (size_t)(p.M * p.J + p.M) * sizeof(float), s>>>(p);
+    }
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+// returns 1 when one of the vectorised thin forward kernels applies
+int ga_thin_conv_supported(const ConvParams& p, int dtype) {
+    const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
+    if (p.M <= 4) {
+        if (p.Cin % 8 || (size_t)p.M * p.J * p.Cin * 4 > 48 * 1024) return 0;
+        if ((long)p.Lout * p.B < 8192) return 0;  // short problems: the wave-per-row kernel has more parallelism
+        if (!aligned16(p.x) || (p.Cin * esz) % 16) return 0;
+        return 1;
+    }
+    if (p.Cin == 1 && p.nphase == 1 && p.M % 8 == 0 && (size_t)(p.M * p.J + p.M) * 4 <= 48 * 1024) {
+        if (!aligned16(p.y) || !aligned16(p.res) || !aligned16(p.dact_src) || (p.M * esz) % 16) return 0;
+        return 1;
+    }
+    return 0;
+}
+int ga_thin_conv_impl(const ConvParams& p, int dtype, hipStream_t s) {
+    return dtype == GA_DTYPE_BF16 ? thin_conv_t<bf16_t>(p, s) : thin_conv_t<float>(p, s);
+}
+
+int ga_thin_wgrad_supported(const WgradParams& p, int dtype) {
+    const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
+    if (p.Cin == 1 && p.M % 8 == 0 && p.M <= 256 && p.J <= 16 && p.in_stride >= 1 && p.in_stride <= 4 &&
+        (p.J - 1) * p.tap_step < 64 && aligned16(p.g) && (p.M * esz) % 16 == 0)
+        return 1;
+    if (p.M == 1 && p.Cin % 8 == 0 && p.Cin <= 2048 && 256 % (p.Cin / 8) == 0 && p.J <= 8 && p.in_stride >= 1 && aligned16(p.x) && (p.Cin * esz) % 16 == 0)
+        return 2;
+    return 0;
+}
+
+template <typename T>
+static int thin_wgrad_t(const WgradParams& p, float* dbias, int kind, hipStream_t s) {
+    if (kind == 1) {
+        const int chunks_per_b = (p.Lout + WG1_ROWS - 1) / WG1_ROWS;
+        wgrad_cin1_kernel<T><<<p.B * chunks_per_b, 256, 0, s>>>(p, dbias, chunks_per_b);
+    } else {
+        int rows_per_block = 256;
+        int gx = (p.Lin + rows_per_block - 1) / rows_per_block;
+        if (gx > 4096) { gx = 4096; rows_per_block = (p.Lin + gx - 1) / gx; }
+        wgrad_m1_kernel<T><<<dim3(gx, p.B), 256, 0, s>>>(p, dbias, rows_per_block);
+    }
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_thin_wgrad_impl(const WgradParams& p, float* dbias, int dtype, int kind, hipStream_t s) {
+    return dtype == GA_DTYPE_BF16 ? thin_wgrad_t<bf16_t>(p, dbias, kind, s) : thin_wgrad_t<float>(p, dbias, kind, s);
+}
+
+int ga_colsum_vec_supported(const void* g, int dtype, int M) {
+    const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
+    return M % 8 == 0 && M <= 2048 && aligned16(g) && (M * esz) % 16 == 0 && 256 % (M / 8) == 0;
+}
+int ga_colsum_vec_impl(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s) {
+    size_t blocks = (rows + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const size_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    if (dtype == GA_DTYPE_BF16)
+        colsum_vec_kernel<bf16_t><<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)g, rows, M, out, rpb);
+    else
+        colsum_vec_kernel<float><<<(unsigned)blocks, 256, 0, s>>>((const float*)g, rows, M, out, rpb);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}

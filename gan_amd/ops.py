@@ -177,18 +177,20 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
     return dx
 
 
-def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor) -> Tensor:
-    """Packed-forward-layout weight gradient [cout, k, cin] (fp32) of a 'conv' layer."""
+def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
+    """Packed-forward-layout weight gradient [cout, k, cin] (fp32) of a 'conv' layer (and the bias gradient [cout],
+    produced by the same C-ABI call, when want_bias)."""
     assert g.kind == "conv"
     L.require_cuda(ga, x)
     assert ga.is_contiguous() and x.is_contiguous() and ga.dtype == x.dtype
     B, lout, cout = ga.shape
     p = L.WgradParams()
     dw = torch.zeros((g.cout, g.k, g.cin), device=x.device, dtype=torch.float32)
-    _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout, Lout=lout, J=g.k,
-          in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
+    db = torch.zeros((g.cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=L.ptr(db), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout,
+          Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
     L.check(L.lib().ga_wgrad(C.byref(p), L.dt(x), _IMPL, L.stream()), "ga_wgrad")
-    return dw
+    return (dw, db) if want_bias else dw
 
 
 # ================================================================================================
@@ -302,9 +304,14 @@ class ConvTrain(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(geom, ga, wp_d, x.shape[1])
+        want_b = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
-            gw = conv_wgrad(geom, ga, x).reshape(-1)
-        if ctx.has_bias and ctx.needs_input_grad[4]:
+            if want_b:
+                gw, gb = conv_wgrad(geom, ga, x, want_bias=True)
+            else:
+                gw = conv_wgrad(geom, ga, x)
+            gw = gw.reshape(-1)
+        elif want_b:
             gb = colsum(ga)
         return gx, None, None, gw, gb, None, None
 

@@ -87,6 +87,8 @@ int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t str
 #define GA_KERNEL_DIRECT_CIN1 2
 #define GA_KERNEL_MFMA_64x128 3  /* conv_mfma_kernel<1,4,32> */
 #define GA_KERNEL_MFMA_128x128 4 /* conv_mfma_kernel<2,2,64> */
+#define GA_KERNEL_THIN_FEWOUT_ROWS 5
+#define GA_KERNEL_THIN_CIN1_VEC 6
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
@@ -97,6 +99,7 @@ typedef struct ga_wgrad_params {
     const void* g; /* [B][LgTot][M] */
     const void* x; /* [B][Lin][Cin] */
     float* dw;     /* [M][J][Cin] */
+    float* dbias;  /* [M] or NULL: when given, dbias[m] += sum_{b,t} g[b][t][m] (bias gradient, atomics) */
     int B, Lin, Cin, M, Lout, J, in_stride, tap_step, off0;
     int LgTot, g_stride, g_phase;
     int rows_per_split; /* set by the library */

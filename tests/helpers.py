@@ -36,3 +36,18 @@ def assert_summary_close(got: torch.Tensor, want: np.ndarray, rtol=1e-4, name=""
     assert abs(g[1] - want[1]) <= rtol * scale + sum_atol, f"{name}: sum {g[1]} vs {want[1]}"
     elem = scale / n  # mean |x|
     np.testing.assert_allclose(g[3:], want[3:], rtol=rtol * 10, atol=(rtol * 10 * elem if elem_atol is None else elem_atol), err_msg=name)
+
+
+def assert_grad_close(got, want, rtol=2e-3, atol_frac=2e-4, max_bad_frac=0.02, l2_tol=1e-2, name=""):
+    """Gradient comparison that tolerates LeakyReLU / hinge / |.| kink flips: an activation within fp32 noise of zero
+    takes the other branch in one implementation and changes the gradient over its receptive field (observed: one flip
+    -> ~430 neighbouring input samples, 1.3 % of the tensor).  Elementwise bound on all but `max_bad_frac` of the
+    elements, plus a relative L2 bound on the whole tensor."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    tol = rtol * np.abs(want) + atol_frac * np.abs(want).max()
+    bad = np.abs(got - want) > tol
+    assert bad.mean() <= max_bad_frac, f"{name}: {bad.mean():.4f} of the elements off"
+    l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+    assert l2 <= l2_tol, f"{name}: relative L2 error {l2:.3e}"
