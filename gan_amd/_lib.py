@@ -44,6 +44,16 @@ class WgradParams(C.Structure):
     ]
 
 
+class LstmParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "bias2", "xg1", "x_in", "y", "h1", "h2", "c1", "c2", "gates1", "gates2",
+                                          "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype")]
+
+
+class LstmBwdParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1t", "w2t", "dy", "gates1", "gates2", "cs1", "cs2", "dg1", "dg2", "dc1", "dc2")] + \
+               [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype")]
+
+
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
@@ -70,6 +80,8 @@ _SIGNATURES = {
     "ga_stft_loss_fwd": [_P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_stft_loss_bwd": [_P, _P, _I, _Z, _I, _I, _P, _P, _P],
     "ga_stft_unpad_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_lstm_fwd": [C.POINTER(LstmParams), _P],
+    "ga_lstm_bwd": [C.POINTER(LstmBwdParams), _P],
     "ga_grad_sqnorm": [_P, _Z, _P, _P],
     "ga_adamw_fused": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _P],
 }

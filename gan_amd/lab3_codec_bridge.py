@@ -7,7 +7,7 @@ same layer stack runs on the gan_amd convolution kernels in channels-last layout
   EncodecConvTranspose1d (:179-233)-> ops.ConvFrozen('convt'): one 2-tap GEMM phase per output residue, right trim implicit
   ELU (:268,330,340)               -> fused as the consumer's load prologue (and ELU' in its data-gradient epilogue)
   EncodecResnetBlock (:252-283)    -> shortcut conv, then k3 conv, then k1 conv whose epilogue adds the shortcut
-  EncodecLSTM (:236-249)           -> torch's LSTM op on ROCm (MIOpen); SURVEY.md section 8(f) lists a HIP LSTM as next-2
+  EncodecLSTM (:236-249)           -> ops.LstmSkip: one k=1 GEMM for the layer-1 input projection + T+1 fused step launches
 Weights are frozen; only the gradient w.r.t. the input latents is produced.  `state_dict()` keys equal the HF
 decoder's, so `SeanetDecoder.load_state_dict(hf_model.decoder.state_dict())` is the integration step
 (loading the checkpoint itself, `EncodecModel.from_pretrained`, stays with the caller: it is a network fetch).
@@ -81,6 +81,7 @@ class SeanetDecoder(nn.Module):
                  precision: str = "fp32"):
         super().__init__()
         self.precision = precision
+        self.use_library_lstm = False  # True: torch's LSTM op (MIOpen) instead of the gan_amd step kernels (A/B checks)
         self.ratios = tuple(int(r) for r in ratios)
         c = (2 ** len(self.ratios)) * num_filters
         layers = nn.Module()
@@ -141,12 +142,18 @@ class SeanetDecoder(nn.Module):
             if kind == "conv":
                 h = self._conv(name, layer, h, dtype)
             elif kind == "lstm":
-                seq = h.permute(1, 0, 2).float()  # [T, B, C]
-                was_training = layer.lstm.training
-                layer.lstm.train(True)  # lab3_codec_bridge.py:140-145: RNN backward needs train mode
-                out, _ = layer.lstm(seq)
-                layer.lstm.train(was_training)
-                h = (out + seq).permute(1, 0, 2).to(dtype).contiguous()
+                if self.use_library_lstm:
+                    seq = h.permute(1, 0, 2).float()  # [T, B, C]
+                    was_training = layer.lstm.training
+                    layer.lstm.train(True)  # lab3_codec_bridge.py:140-145: RNN backward needs train mode
+                    out, _ = layer.lstm(seq)
+                    layer.lstm.train(was_training)
+                    h = (out + seq).permute(1, 0, 2).to(dtype).contiguous()
+                else:
+                    key = ("lstm", dtype)
+                    if key not in self._packs:
+                        self._packs[key] = ops.prepare_lstm_weights(layer.lstm, dtype)
+                    h = ops.LstmSkip.apply(h, self._packs[key])
             elif kind == "elu_convt":
                 h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
             elif kind == "resblock":

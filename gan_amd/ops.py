@@ -596,3 +596,77 @@ class StftSums(torch.autograd.Function):
         L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.dt(dxp), L.dt(dx), B, S, n_fft, hop, rows, 0, L.stream()),
                 "ga_stft_unpad_bwd")
         return dx.to(ctx.in_dtype), None, None, None, None, None
+
+
+# ================================================================================================
+class LstmSkip(torch.autograd.Function):
+    """y = LSTM2(x) + x for the frozen decoder (HF EncodecLSTM); x, y: [B, T, H] channels-last.
+    `w` is the dict prepared by prepare_lstm_weights (frozen, cached by the decoder)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        L.require_cuda(x)
+        x = x.contiguous()
+        B, T, H = x.shape
+        dtype = x.dtype
+        wd = w["dtype"]
+        assert wd == dtype, "LSTM weights must be prepared in the activation dtype"
+        geom = w["geom_ih0"]
+        xg1 = conv_forward(geom, x, w["ih0_f"], w["bias1"])
+        need_grad = x.requires_grad
+        dev = x.device
+        y = torch.empty_like(x)
+        h1 = torch.empty((B, T, H), device=dev, dtype=dtype)
+        h2 = torch.empty((B, T, H), device=dev, dtype=dtype)
+        c = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
+        gates = torch.empty((2, B, T, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
+        cs = torch.empty((2, B, T, H), device=dev, dtype=torch.float32) if need_grad else None
+        p = L.LstmParams()
+        _fill(p, w1=w["hh0"].data_ptr(), w2=w["cat1"].data_ptr(), bias2=w["bias2"].data_ptr(), xg1=xg1.data_ptr(),
+              x_in=x.data_ptr(), y=y.data_ptr(), h1=h1.data_ptr(), h2=h2.data_ptr(), c1=c[0].data_ptr(), c2=c[1].data_ptr(),
+              gates1=L.ptr(gates[0]) if need_grad else 0, gates2=L.ptr(gates[1]) if need_grad else 0,
+              cs1=L.ptr(cs[0]) if need_grad else 0, cs2=L.ptr(cs[1]) if need_grad else 0, B=B, T=T, H=H,
+              act_dtype=L.dt(x), w_dtype=L.dt(h1))
+        L.check(L.lib().ga_lstm_fwd(C.byref(p), L.stream()), "ga_lstm_fwd")
+        if need_grad:
+            ctx.save_for_backward(gates, cs)
+        ctx.w = w
+        ctx.shape = (B, T, H)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gates, cs = ctx.saved_tensors
+        w = ctx.w
+        B, T, H = ctx.shape
+        dy = dy.contiguous()
+        dev, dtype = dy.device, dy.dtype
+        dg = torch.empty((2, B, T, 4 * H), device=dev, dtype=dtype)
+        dc = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
+        p = L.LstmBwdParams()
+        _fill(p, w1t=w["hh0_t"].data_ptr(), w2t=w["cat1_t"].data_ptr(), dy=dy.data_ptr(), gates1=gates[0].data_ptr(),
+              gates2=gates[1].data_ptr(), cs1=cs[0].data_ptr(), cs2=cs[1].data_ptr(), dg1=dg[0].data_ptr(), dg2=dg[1].data_ptr(),
+              dc1=dc[0].data_ptr(), dc2=dc[1].data_ptr(), B=B, T=T, H=H, act_dtype=L.dt(dy), w_dtype=L.dt(dg))
+        L.check(L.lib().ga_lstm_bwd(C.byref(p), L.stream()), "ga_lstm_bwd")
+        dx = conv_dgrad(w["geom_ih0"], dg[0], w["ih0_d"], T, res=dy)  # dg1 @ W_ih_l0 + dy (skip path)
+        return dx, None
+
+
+def prepare_lstm_weights(lstm: torch.nn.LSTM, dtype: torch.dtype) -> dict:
+    """Frozen nn.LSTM(H, H, 2) parameters -> the layouts ga_lstm_fwd / ga_lstm_bwd stream (done once per dtype)."""
+    if lstm.num_layers != 2 or lstm.bidirectional or lstm.input_size != lstm.hidden_size:
+        raise ValueError("expected nn.LSTM(H, H, num_layers=2)")
+    H = lstm.hidden_size
+    with torch.no_grad():
+        ih0, hh0 = lstm.weight_ih_l0.detach().float(), lstm.weight_hh_l0.detach().float()
+        ih1, hh1 = lstm.weight_ih_l1.detach().float(), lstm.weight_hh_l1.detach().float()
+        geom = ConvGeom("conv", H, 4 * H, 1)
+        w3 = ih0.reshape(4 * H, H, 1).contiguous()
+        return {
+            "dtype": dtype, "geom_ih0": geom,
+            "ih0_f": pack_weight(geom, w3, geom.fwd_pack, dtype), "ih0_d": pack_weight(geom, w3, geom.dgrad_pack, dtype),
+            "bias1": (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().float().contiguous(),
+            "hh0": hh0.to(dtype).contiguous(), "cat1": torch.cat([ih1, hh1], dim=1).to(dtype).contiguous(),
+            "bias2": (lstm.bias_ih_l1 + lstm.bias_hh_l1).detach().float().contiguous(),
+            "hh0_t": hh0.t().to(dtype).contiguous(), "cat1_t": torch.cat([ih1.t(), hh1.t()], dim=0).to(dtype).contiguous(),
+        }

@@ -193,6 +193,38 @@ int ga_adamw_fused(float* p, float* g, float* m, float* v, size_t n, float lr, f
                    float weight_decay, int step, float max_norm, float grad_scale, const float* sqnorm,
                    int write_clipped_grad, ga_stream_t stream);
 
+/* Two-layer LSTM + input skip of the frozen decoder (HF EncodecLSTM, modeling_encodec.py:236-249; reached through
+ * lab3_codec_bridge.py:143).  All [B][T][*] buffers are channels-last.  Gate order i,f,g,o (torch nn.LSTM).
+ * forward: T+1 dependent step launches covering both layers (layer 2 one step behind layer 1).
+ *   w1 = weight_hh_l0 [4H][H]; w2 = [weight_ih_l1 | weight_hh_l1] [4H][2H]; bias2 = bias_ih_l1 + bias_hh_l1
+ *   xg1 = x @ weight_ih_l0^T + bias_ih_l0 + bias_hh_l0 for all steps (one ga_conv with k=1)
+ *   y = h2 + x_in.  c1, c2 are the running cell states (caller zeroes).  gatesN and csN (all or none) save i,f,g,o and c
+ *   for the backward pass.  w_dtype/act_dtype: both bf16 or both f32. */
+typedef struct ga_lstm_params {
+    const void* w1; const void* w2; const float* bias2;
+    const void* xg1;  /* [B][T][4H] act dtype */
+    const void* x_in; /* [B][T][H] act dtype */
+    void* y;          /* [B][T][H] act dtype */
+    void* h1; void* h2; /* [B][T][H] w dtype: hidden-state history of the two layers */
+    float* c1; float* c2; /* [B][H] */
+    float* gates1; float* gates2; /* [B][T][4H] or NULL */
+    float* cs1; float* cs2;       /* [B][T][H] or NULL */
+    int B, T, H, act_dtype, w_dtype;
+} ga_lstm_params;
+int ga_lstm_fwd(const ga_lstm_params* h_params, ga_stream_t stream);
+/* backward w.r.t. the input only (weights are frozen): fills dg1 = d(loss)/d(gate pre-activations of layer 1) for all
+ * steps; dx = dg1 @ weight_ih_l0 + dy is one more ga_conv (k=1, residual epilogue).
+ *   w1t = weight_hh_l0^T [H][4H]; w2t = [weight_ih_l1^T ; weight_hh_l1^T] [2H][4H]; dc1, dc2 [B][H] zeroed by the caller */
+typedef struct ga_lstm_bwd_params {
+    const void* w1t; const void* w2t;
+    const void* dy; /* [B][T][H] act dtype */
+    const float* gates1; const float* gates2; const float* cs1; const float* cs2;
+    void* dg1; void* dg2; /* [B][T][4H] w dtype */
+    float* dc1; float* dc2;
+    int B, T, H, act_dtype, w_dtype;
+} ga_lstm_bwd_params;
+int ga_lstm_bwd(const ga_lstm_bwd_params* h_params, ga_stream_t stream);
+
 /* library identification: returns the gfx target the code objects were built for ("gfx950") */
 const char* ga_build_target(void);
 

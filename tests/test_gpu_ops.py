@@ -293,3 +293,29 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
     close(sd["state"][2]["exp_avg"], opt_ref.state_dict()["state"][2]["exp_avg"], 1e-5, "exp_avg")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("B,T", [(3, 20), (18, 7)])
+def test_lstm_skip_matches_torch_lstm(B, T, dtype):
+    """ga_lstm_fwd / ga_lstm_bwd (fused two-layer step kernels) against torch.nn.LSTM on the CPU."""
+    torch.manual_seed(10)
+    H = 512
+    lstm = torch.nn.LSTM(H, H, 2)
+    x = torch.randn(B, T, H) * 0.7
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    seq = xr.permute(1, 0, 2)
+    y_ref = (lstm(seq)[0] + seq).permute(1, 0, 2)
+    gy = torch.randn_like(y_ref)
+    gx_ref, = torch.autograd.grad(y_ref, xr, gy)
+    w = ops.prepare_lstm_weights(lstm.to(DEV), dtype)
+    xg = x.to(DEV, dtype).requires_grad_(True)
+    y = ops.LstmSkip.apply(xg, w)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    close(y, y_ref, tol, "lstm fwd")
+    gx, = torch.autograd.grad(y, xg, gy.to(DEV, dtype))
+    close(gx, gx_ref, tol, "lstm bwd")
+    with torch.no_grad():  # inference path (no saved gates)
+        close(ops.LstmSkip.apply(x.to(DEV, dtype), w), y_ref, tol, "lstm fwd nograd")
