@@ -31,7 +31,7 @@ class ConvParams(C.Structure):
         ("out_stride", C.c_int), ("t0", C.c_int),
         ("pad_mode", C.c_int), ("pre_act", C.c_int), ("post_act", C.c_int), ("dact_mode", C.c_int),
         ("accumulate", C.c_int), ("nphase", C.c_int),
-        ("phase_off0", C.c_int * GA_MAX_PHASE),
+        ("phase_off0", C.c_int * GA_MAX_PHASE), ("out_f32", C.c_int),
     ]
 
 

@@ -21,8 +21,10 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     if (impl == GA_IMPL_MFMA) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
-    if (impl == GA_IMPL_AUTO && can_mfma && (long)p.Lout * p.B >= 64) return ga_conv_mfma_impl(p, s);
+    if (impl == GA_IMPL_AUTO && can_mfma && ((long)p.Lout * p.B >= 64 || p.out_f32)) return ga_conv_mfma_impl(p, s);
     if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) return GA_ERR_ARG;
+    const bool want_f32_out = p.out_f32 && dtype == GA_DTYPE_BF16;
+    if (want_f32_out && !(p.in_stride >= 1 && ga_thin_conv_supported(p, dtype))) return GA_ERR_ARG;  // only MFMA / thin rows kernels
     if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) {
         if (!p.x || !p.w || !p.y || p.nphase < 1 || p.nphase > GA_MAX_PHASE || (long)p.B * p.nphase > 65535) return GA_ERR_ARG;
         return p.Lout > 0 ? ga_thin_conv_impl(p, dtype, s) : GA_OK;
@@ -34,7 +36,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (!hp) return -1;
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
-    const bool mfma = (impl == GA_IMPL_MFMA && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && (long)p.Lout * p.B >= 64);
+    const bool mfma = (impl == GA_IMPL_MFMA && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && ((long)p.Lout * p.B >= 64 || p.out_f32));
     if (mfma) return p.M <= 64 ? GA_KERNEL_MFMA_64x128 : GA_KERNEL_MFMA_128x128;
     if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) return p.M <= 4 ? GA_KERNEL_THIN_FEWOUT_ROWS : GA_KERNEL_THIN_CIN1_VEC;
     if (p.M <= 4) return GA_KERNEL_DIRECT_FEWOUT;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(ConvParams p, i
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    const int nchunks = p.Cin / CC;
+    const int nchunks = (p.Cin + CC - 1) / CC;
     const int nsteps = nchunks * p.J;
     bf16x8 wreg[PW];
 
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(ConvParams p, i
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-            if (q < BM * 4 && mbase + m < p.M)
+            if (q < BM * 4 && mbase + m < p.M && ch * CC + part * 8 < p.Cin)
                 v = *(const bf16x8*)(w + ((size_t)(mbase + m) * p.J + j) * p.Cin + ch * CC + part * 8);
             wreg[i] = v;
         }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(ConvParams p, i
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-            if (R >= 0 && R < p.Lin) v = apply_pre(*(const bf16x8*)(x + (size_t)R * p.Cin + ch * CC + part * 8), p.pre_act);
+            if (R >= 0 && R < p.Lin && ch * CC + part * 8 < p.Cin) v = apply_pre(*(const bf16x8*)(x + (size_t)R * p.Cin + ch * CC + part * 8), p.pre_act);
             const int ph = u % S, idx = u / S;
             *(bf16x8*)(Xl + (ph * rpp + idx) * PITCH + part * 16) = v;
         }
@@ -184,10 +184,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(ConvParams p, i
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += (float)d[i];
                 }
-                bf16x4 o;
+                if (p.out_f32) {
+                    *(float4*)((float*)p.y + rowbase + m0) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-                *(bf16x4*)(y + rowbase + m0) = o;
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+                    *(bf16x4*)(y + rowbase + m0) = o;
+                }
             }
         }
     }
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(ConvParams p, i
 
 // ------------------------------------------------------------------------------------------------
 int ga_conv_mfma_supported(const ConvParams& p) {
-    if (p.Cin % CC || p.M % 4 || p.M < 32 || p.in_stride < 1 || p.tap_step < 0) return 0;
+    if (p.Cin % 8 || p.Cin < 16 || p.M % 4 || p.M < 16 || p.in_stride < 1 || p.tap_step < 0) return 0;
+    if (p.out_f32 && (p.res || p.dact_src || p.accumulate)) return 0;
     if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
     const int span = 127 * p.in_stride + (p.J - 1) * p.tap_step + 1;
     const int rpp = (span + p.in_stride - 1) / p.in_stride + 1;

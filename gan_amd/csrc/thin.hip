@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(ConvParams p) {
             v = act_apply(p.post_act, v);
             if (p.dact_mode) v *= dact_apply(p.dact_mode, (float)((const T*)p.dact_src)[idx]);
             if (p.res) v += (float)((const T*)p.res)[idx];
+            if (p.out_f32) { ((float*)p.y)[idx] = v; continue; }
             if (p.accumulate) v += (float)((T*)p.y)[idx];
             ((T*)p.y)[idx] = (T)v;
         }
@@ -326,10 +327,12 @@ int ga_thin_conv_supported(const ConvParams& p, int dtype) {
     const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
     if (p.M <= 4) {
         if (p.Cin % 8 || (size_t)p.M * p.J * p.Cin * 4 > 48 * 1024) return 0;
-        if ((long)p.Lout * p.B < 8192) return 0;  // short problems: the wave-per-row kernel has more parallelism
+        if (p.out_f32 && (p.res || p.dact_src || p.accumulate)) return 0;
+        if ((long)p.Lout * p.B < 8192 && !p.out_f32) return 0;  // short problems: the wave-per-row kernel has more parallelism
         if (!aligned16(p.x) || (p.Cin * esz) % 16) return 0;
         return 1;
     }
+    if (p.out_f32) return 0;
     if (p.Cin == 1 && p.nphase == 1 && p.M % 8 == 0 && (size_t)(p.M * p.J + p.M) * 4 <= 48 * 1024) {
         if (!aligned16(p.y) || !aligned16(p.res) || !aligned16(p.dact_src) || (p.M * esz) % 16) return 0;
         return 1;

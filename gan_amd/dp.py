@@ -21,17 +21,20 @@ import torch.distributed as dist
 
 
 class _AllReduceSums(torch.autograd.Function):
-    """forward: SUM over ranks; backward: identity (each rank's sums enter the global value with weight 1)."""
+    """forward: SUM over ranks.  backward: gradient times world_size - every rank then holds d(GLOBAL loss)/d(its own
+    shard) * W, and the optimizer's mean over ranks (grad_scale = 1/W) turns the sum of those partial gradients into the
+    full-batch gradient, on the same footing as the per-rank-mean loss terms."""
 
     @staticmethod
     def forward(ctx, t, group):
         out = t.clone()
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        ctx.world = dist.get_world_size(group)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return g * float(ctx.world), None
 
 
 class DataParallel:
@@ -66,9 +69,6 @@ class DataParallel:
     def stft_sum_hook(self, sums: torch.Tensor, count: float):
         if not self.exact_stft or self.world_size == 1:
             return sums, count
-        # every rank's loss is the GLOBAL loss; its local gradient is d(global)/d(local x).  The optimizer averages
-        # gradients over ranks, so scale this term by world_size to keep sum-over-ranks semantics of the other
-        # (per-rank mean) terms consistent: mean_r(W * dL/dx_r) == dL_global/dx_r summed as the reference would.
         g = _AllReduceSums.apply(sums, self.group)
         return g, count * self.world_size
 

@@ -128,9 +128,9 @@ class SeanetDecoder(nn.Module):
             self._packs[key] = ops.pack_frozen(layer.geom, layer.conv.v.data, layer.conv.g.data, dtype)
         return self._packs[key]
 
-    def _conv(self, name: str, layer: _ConvLayer, x, dtype, pre_act=L.ACT_NONE, res=None):
+    def _conv(self, name: str, layer: _ConvLayer, x, dtype, pre_act=L.ACT_NONE, res=None, out_f32=False):
         wp_f, wp_d = self._pack(name, layer, dtype)
-        return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act)
+        return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act, out_f32)
 
     def forward(self, q_bct: torch.Tensor) -> torch.Tensor:
         """q [B, 128, T] -> wav [B, 1, T*prod(ratios)]"""
@@ -161,7 +161,8 @@ class SeanetDecoder(nn.Module):
                 t = self._conv(name + ".b1", getattr(layer.block, "1"), h, dtype, pre_act=L.ACT_ELU)
                 h = self._conv(name + ".b3", getattr(layer.block, "3"), t, dtype, pre_act=L.ACT_ELU, res=sc)
             elif kind == "elu_conv":
-                h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
+                # the waveform leaves the decoder in fp32 even in bf16 mode: the MR-STFT log-magnitude loss reads it
+                h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU, out_f32=True)
         return h.permute(0, 2, 1)  # [B, 1, S]
 
 

@@ -145,7 +145,7 @@ def _safe_sqrt(s: torch.Tensor) -> torch.Tensor:
 
 
 def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolutions: Iterable[Tuple[int, int, int]],
-                          sum_hook=None) -> torch.Tensor:
+                          sum_hook=None, precision: str = "fp32") -> torch.Tensor:
     """reference :148-176.  Per resolution one fused pass yields [sum (my-mx)^2, sum my^2, sum |log mx - log my|];
     `sum_hook` (data parallel) may all-reduce those sums so the spectral-convergence ratio is the global-batch one."""
     if wav_pred.shape != wav_true.shape:
@@ -160,7 +160,7 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
         n_fft, hop, win = int(n_fft), int(hop), int(win)
         if S < n_fft:
             continue
-        sums = ops.StftSums.apply(x, y, n_fft, hop, win, True)
+        sums = ops.StftSums.apply(x, y, n_fft, hop, win, precision == "bf16")
         count = float(B * (n_fft // 2 + 1) * (1 + S // hop))
         if sum_hook is not None:
             sums, count = sum_hook(sums, count)
@@ -272,7 +272,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     loss_fm = multiscale_feature_matching_loss(real_outs=real_outs_g, fake_outs=fake_outs)
     loss_lat_l1, loss_lat_cont, loss_delta_budget = latent_losses(q_hat, q_src, float(stage_cfg.delta_budget))
     loss_mrstft = _waveform_mrstft_loss(wav_pred=x_hat, wav_true=x_src, resolutions=stage_cfg.wave_mrstft_resolutions,
-                                        sum_hook=None if dp is None else dp.stft_sum_hook)
+                                        sum_hook=None if dp is None else dp.stft_sum_hook,
+                                        precision=getattr(generator, "precision", "fp32"))
     zero = torch.zeros((), device=device)
     loss_content = zero
     loss_style = zero

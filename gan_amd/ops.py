@@ -117,7 +117,11 @@ def dgrad_params(g: ConvGeom, B: int, lin: int) -> L.ConvParams:
 def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, res=None, dact_src=None, impl=L.IMPL_AUTO):
     L.require_cuda(x, w, y)
     assert x.is_contiguous() and w.is_contiguous() and y.is_contiguous()
-    assert x.dtype == w.dtype == y.dtype, (x.dtype, w.dtype, y.dtype)
+    assert x.dtype == w.dtype, (x.dtype, w.dtype)
+    if p.out_f32 and x.dtype == torch.bfloat16:
+        assert y.dtype == torch.float32 and res is None and dact_src is None
+    else:
+        assert y.dtype == x.dtype, (x.dtype, y.dtype)
     assert x.numel() == p.B * p.Lin * p.Cin, (x.shape, p.B, p.Lin, p.Cin)
     assert y.numel() == p.B * p.LoutTot * p.M, (y.shape, p.B, p.LoutTot, p.M)
     assert w.numel() >= p.nphase * p.M * p.J * p.Cin
@@ -150,12 +154,14 @@ def set_conv_impl(impl: int) -> None:
     _IMPL = impl
 
 
-def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None) -> Tensor:
+def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None,
+                 out_f32: bool = False) -> Tensor:
     B, lin, cin = x.shape
     assert cin == g.cin, (cin, g.cin)
     p = fwd_params(g, B, lin)
     p.pre_act, p.post_act = pre_act, post_act
-    y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=x.dtype)
+    p.out_f32 = 1 if (out_f32 and x.dtype == torch.bfloat16) else 0
+    y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=torch.float32 if p.out_f32 else x.dtype)
     _launch_conv(p, x, wp, y, bias=bias, res=res, impl=_IMPL)
     return y
 
@@ -321,10 +327,11 @@ class ConvFrozen(torch.autograd.Function):
     dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
 
     @staticmethod
-    def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int):
+    def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False):
         x = x.contiguous()
-        y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous())
+        y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
         ctx.geom, ctx.pre_act = geom, pre_act
+        ctx.x_dtype = x.dtype
         ctx.save_for_backward(x if pre_act else None, wp_d)
         ctx.lin = x.shape[1]
         return y
@@ -332,7 +339,7 @@ class ConvFrozen(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, wp_d = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = gy.contiguous().to(ctx.x_dtype)
         gx = None
         if ctx.needs_input_grad[0]:
             if ctx.pre_act == L.ACT_ELU:
@@ -342,7 +349,7 @@ class ConvFrozen(torch.autograd.Function):
             else:
                 raise NotImplementedError
         gres = gy if ctx.needs_input_grad[1] else None
-        return gx, gres, None, None, None, None, None
+        return gx, gres, None, None, None, None, None, None
 
 
 # ================================================================================================
@@ -547,53 +554,58 @@ def _dft_basis(n_fft: int, hop: int, win: int, dtype: torch.dtype, device, rep: 
 
 
 class StftSums(torch.autograd.Function):
-    """[sum (my-mx)^2, sum my^2, sum |log mx - log my|, n_bins_total] for one resolution; x, y: [B, S]."""
+    """[sum (my-mx)^2, sum my^2, sum |log mx - log my|] for one resolution; x, y: [B, S].
+    split=False: exact fp32 DFT GEMM (direct kernel).  split=True: bf16 MFMA GEMM on the hi/lo split of the fp32 signal
+    and basis (x*b ~= xhi*bhi + xlo*bhi + xhi*blo, i.e. 3x the K extent, ~2^-16 relative error) with fp32 output; the
+    magnitude / log / reduction kernels are fp32 either way."""
 
     @staticmethod
     def forward(ctx, x, y, n_fft: int, hop: int, win: int, split: bool):
         L.require_cuda(x, y)
         ctx.in_dtype = x.dtype
-        x = x.contiguous().float()  # the DFT GEMM runs in exact fp32 (direct kernel) in this version
+        x = x.contiguous().float()
         y = y.contiguous().float()
         B, S = x.shape
         lib = L.lib()
-        dtype = x.dtype
-        rep = 3 if (split and dtype == torch.bfloat16) else 1
-        w_f, w_d, nb, M, J = _dft_basis(n_fft, hop, win, dtype, x.device, rep)
+        gdt = torch.bfloat16 if split else torch.float32
+        rep = 3 if split else 1
+        w_f, w_d, nb, M, J = _dft_basis(n_fft, hop, win, gdt, x.device, rep)
         P = n_fft // 2
         rows = (S + 2 * P + hop - 1) // hop
         frames = 1 + S // hop
         specs = []
         for sig in (x, y):
-            xp = torch.empty((B, rows, hop * rep), device=x.device, dtype=dtype)
+            xp = torch.empty((B, rows, hop * rep), device=x.device, dtype=gdt)
             L.check(lib.ga_stft_pad(sig.data_ptr(), xp.data_ptr(), L.dt(sig), L.dt(xp), B, S, n_fft, hop, rows, rep, L.stream()), "ga_stft_pad")
             p = _new_params()
-            _fill(p, B=B, Lin=rows, Cin=hop * rep, M=M, Lout=frames, LoutTot=frames, J=J, off0=0)
-            spec = torch.empty((B, frames, M), device=x.device, dtype=dtype)
+            _fill(p, B=B, Lin=rows, Cin=hop * rep, M=M, Lout=frames, LoutTot=frames, J=J, off0=0, out_f32=1 if split else 0)
+            spec = torch.empty((B, frames, M), device=x.device, dtype=torch.float32)
             _launch_conv(p, xp, w_f, spec, impl=_IMPL)
             specs.append(spec)
         out = torch.zeros((3,), device=x.device, dtype=torch.float32)
-        L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.dt(specs[0]), B * frames, nb, M, out.data_ptr(),
+        L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.DT_F32, B * frames, nb, M, out.data_ptr(),
                                      L.stream()), "ga_stft_loss_fwd")
         ctx.save_for_backward(specs[0], specs[1], w_d)
-        ctx.cfg = (B, S, n_fft, hop, rows, frames, nb, M, J)
+        ctx.cfg = (B, S, n_fft, hop, rows, frames, nb, M, J, split)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         sx, sy, w_d = ctx.saved_tensors
-        B, S, n_fft, hop, rows, frames, nb, M, J = ctx.cfg
+        B, S, n_fft, hop, rows, frames, nb, M, J, split = ctx.cfg
         lib = L.lib()
         gout = gout.contiguous().float()
         dsx = torch.empty_like(sx)
-        L.check(lib.ga_stft_loss_bwd(sx.data_ptr(), sy.data_ptr(), L.dt(sx), B * frames, nb, M, gout.data_ptr(), dsx.data_ptr(),
+        L.check(lib.ga_stft_loss_bwd(sx.data_ptr(), sy.data_ptr(), L.DT_F32, B * frames, nb, M, gout.data_ptr(), dsx.data_ptr(),
                                      L.stream()), "ga_stft_loss_bwd")
+        if split:
+            dsx = dsx.to(torch.bfloat16)  # MFMA operand; accumulation and the output stay fp32
         p = _new_params()
-        _fill(p, B=B, Lin=frames, Cin=M, M=hop, Lout=rows, LoutTot=rows, J=J, off0=-(J - 1))
-        dxp = torch.empty((B, rows, hop), device=sx.device, dtype=sx.dtype)
+        _fill(p, B=B, Lin=frames, Cin=M, M=hop, Lout=rows, LoutTot=rows, J=J, off0=-(J - 1), out_f32=1 if split else 0)
+        dxp = torch.empty((B, rows, hop), device=sx.device, dtype=torch.float32)
         _launch_conv(p, dsx, w_d, dxp, impl=_IMPL)
-        dx = torch.empty((B, S), device=sx.device, dtype=sx.dtype)
-        L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.dt(dxp), L.dt(dx), B, S, n_fft, hop, rows, 0, L.stream()),
+        dx = torch.empty((B, S), device=sx.device, dtype=torch.float32)
+        L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.DT_F32, L.DT_F32, B, S, n_fft, hop, rows, 0, L.stream()),
                 "ga_stft_unpad_bwd")
         return dx.to(ctx.in_dtype), None, None, None, None, None
 

@@ -72,6 +72,8 @@ typedef struct ga_conv_params {
     int pad_mode, pre_act, post_act, dact_mode, accumulate;
     int nphase;
     int phase_off0[GA_MAX_PHASE];
+    int out_f32; /* bf16 problems only: write y as fp32 (no res / dact_src / accumulate); used by the STFT GEMM and the
+                    decoder's waveform output so that loss arithmetic downstream sees unrounded values */
 } ga_conv_params;
 
 /* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients

@@ -89,6 +89,22 @@ def test_mrstft_edge_cases_match_reference_golden(golden):
         float(golden["mrstft/stress"]), rel=1e-4)
 
 
+def test_mrstft_bf16_split_gemm_tracks_fp32(golden):
+    """bf16-mode MR-STFT (hi/lo split MFMA GEMM, fp32 out): loss within 2e-4, gradient within 2e-2 (L2) of the fp32 path."""
+    from gan_amd.lab3_codec_train import _waveform_mrstft_loss
+    from oracle.procfill import proc_input
+    x = proc_input((2, 1, 24000), "stft.x", 0, 0.5).to(DEV).requires_grad_(True)
+    y = proc_input((2, 1, 24000), "stft.y", 0, 0.5).to(DEV)
+    outs = []
+    for prec in ("fp32", "bf16"):
+        l = _waveform_mrstft_loss(x, y, O.DEFAULT_RESOLUTIONS, precision=prec)
+        g, = torch.autograd.grad(l, x)
+        outs.append((float(l), g))
+    assert outs[1][0] == pytest.approx(outs[0][0], rel=2e-4)
+    err = (outs[1][1] - outs[0][1]).norm() / outs[0][1].norm()
+    assert float(err) < 2e-2, float(err)
+
+
 def test_discriminator_only_odd_lengths_and_param_grads(golden, state):
     from oracle.procfill import proc_input
     _, d_sd, _ = state
