@@ -5,6 +5,8 @@ int ga_conv_direct_impl(const ConvParams& p, int dtype, hipStream_t s);
 int ga_wgrad_direct_impl(const WgradParams& p, int dtype, hipStream_t s);
 int ga_conv_mfma_supported(const ConvParams& p);
 int ga_conv_mfma_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_gemm_supported(const ConvParams& p);
+int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s);
 int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
 int ga_thin_conv_supported(const ConvParams& p, int dtype);
@@ -20,8 +22,13 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     if (dtype != GA_DTYPE_F32 && dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
-    if (impl == GA_IMPL_MFMA) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
-    if (impl == GA_IMPL_AUTO && can_mfma && ((long)p.Lout * p.B >= 64 || p.out_f32)) return ga_conv_mfma_impl(p, s);
+    const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
+    if (impl == GA_IMPL_MFMA_WINDOW) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
+    if (impl == GA_IMPL_MFMA) return can_gemm ? ga_conv_gemm_impl(p, s) : can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
+    if (impl == GA_IMPL_AUTO && ((long)p.Lout * p.B >= 64 || p.out_f32)) {
+        if (can_gemm) return ga_conv_gemm_impl(p, s);
+        if (can_mfma) return ga_conv_mfma_impl(p, s);
+    }
     if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) return GA_ERR_ARG;
     const bool want_f32_out = p.out_f32 && dtype == GA_DTYPE_BF16;
     if (want_f32_out && !(p.in_stride >= 1 && ga_thin_conv_supported(p, dtype))) return GA_ERR_ARG;  // only MFMA / thin rows kernels
@@ -36,7 +43,10 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (!hp) return -1;
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
-    const bool mfma = (impl == GA_IMPL_MFMA && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && ((long)p.Lout * p.B >= 64 || p.out_f32));
+    const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
+    const bool big = (long)p.Lout * p.B >= 64 || p.out_f32;
+    if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
+    const bool mfma = ((impl == GA_IMPL_MFMA || impl == GA_IMPL_MFMA_WINDOW) && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && big);
     if (mfma) return p.M <= 64 ? GA_KERNEL_MFMA_64x128 : GA_KERNEL_MFMA_128x128;
     if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) return p.M <= 4 ? GA_KERNEL_THIN_FEWOUT_ROWS : GA_KERNEL_THIN_CIN1_VEC;
     if (p.M <= 4) return GA_KERNEL_DIRECT_FEWOUT;

@@ -46,7 +46,8 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 
 #define GA_IMPL_AUTO 0   /* MFMA for bf16 when the shape fills tiles, else direct */
 #define GA_IMPL_DIRECT 1 /* vector-ALU fp32 FMA chains (exact fp32 mode, thin layers) */
-#define GA_IMPL_MFMA 2   /* bf16 MFMA implicit GEMM; error if the shape is unsupported */
+#define GA_IMPL_MFMA 2   /* bf16 MFMA implicit GEMM (gathered-GEMM kernel when it applies, else the window kernel); error if unsupported */
+#define GA_IMPL_MFMA_WINDOW 3 /* force the LDS-window MFMA kernel (conv_mfma_kernel) */
 
 #define GA_MAX_PHASE 8
 
@@ -91,6 +92,8 @@ int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t str
 #define GA_KERNEL_MFMA_128x128 4 /* conv_mfma_kernel<2,2,64> */
 #define GA_KERNEL_THIN_FEWOUT_ROWS 5
 #define GA_KERNEL_THIN_CIN1_VEC 6
+#define GA_KERNEL_GEMM_64x256 7  /* conv_gemm_kernel<1,4> */
+#define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2> */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]

@@ -123,6 +123,48 @@ def test_mfma_path_is_taken_and_matches_direct():
                 close(outs[0], outs[1].float().cpu(), 1.5e-2, f"{g} {mode}")
 
 
+GEMM_CASES = [
+    # geom, L, B -- every geometry family the gathered-GEMM kernel serves (pre_act none), ragged N and M tiles
+    (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 3),     # D block 1: 64x256 tile, two taps per K-step
+    (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 2050, 2),    # D block 2
+    (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 469, 3),    # D block 4: N flattened over the batch, ragged tiles
+    (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 3),      # G dilated conv
+    (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 37, 5),       # short rows: tiles span several batch items
+    (ConvGeom("conv", 16, 48, 5, 2, 2, 1), 301, 2),        # Cin 16 (four taps per K-step), M = 48, K not a multiple of 64
+    (ConvGeom("convt", 128, 64, 8, 4), 300, 2),            # transposed conv: phases
+    (ConvGeom("convt", 512, 256, 16, 8), 40, 2),
+    (ConvGeom("cconv", 128, 512, 7), 375, 2),              # causal reflect conv (dgrad needs the mirrored fix-up launch)
+    (ConvGeom("cconv", 64, 128, 1), 500, 2),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=lambda c: f"{c[0].kind}-{c[0].cin}-{c[0].cout}-k{c[0].k}s{c[0].stride}d{c[0].dilation}-L{c[1]}")
+def test_gathered_gemm_kernel_matches_window_and_direct(case):
+    """conv_gemm_kernel (direct-to-LDS gathered GEMM) must be the kernel AUTO picks for these shapes and must agree
+    with the direct fp32-FMA kernel on the same bf16 operands, forward and data gradient."""
+    g, Ln, B = case
+    torch.manual_seed(12)
+    x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+    d0, d1, k = g.wdims
+    w = torch.randn(d0, d1, k, device=DEV) / (g.cin * g.k) ** 0.5
+    bias = torch.randn(g.cout, device=DEV)
+    gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+    p = ops.fwd_params(g, B, Ln)
+    kid = L.lib().ga_conv_kernel_id(__import__("ctypes").byref(p), 1, L.IMPL_AUTO)
+    assert kid in (L.KERNEL_GEMM_64x256, L.KERNEL_GEMM_128x128), kid
+    outs = {}
+    for impl in (L.IMPL_MFMA, L.IMPL_DIRECT):
+        ops.set_conv_impl(impl)
+        try:
+            yf = ops.conv_forward(g, x, ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), bias, post_act=L.ACT_LRELU)
+            dx = ops.conv_dgrad(g, gy, ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16), Ln)
+            outs[impl] = (yf.float().cpu(), dx.float().cpu())
+        finally:
+            ops.set_conv_impl(L.IMPL_AUTO)
+    close(outs[L.IMPL_MFMA][0], outs[L.IMPL_DIRECT][0], 1e-2, f"{g} fwd")
+    close(outs[L.IMPL_MFMA][1], outs[L.IMPL_DIRECT][1], 1e-2, f"{g} dgrad")
+
+
 def test_mfma_weight_gradient_matches_direct():
     """bf16 weight gradient: transposed-LDS-read MFMA kernel against the direct kernel on the same bf16 operands."""
     torch.manual_seed(9)
