@@ -264,10 +264,38 @@ __global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
 }
 
 // ga = gy * act'(.) : mode LRELU_FROM_OUT uses the post-activation output
+// 16 bytes per lane per access (EV = 4 floats / 8 bf16); the last n % EV elements are handled by thread 0 of block 0.
+template <typename T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
+
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ src, T* __restrict__ ga, size_t n, int mode) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        ga[i] = (T)((float)gy[i] * dact_apply(mode, (float)src[i]));
+    constexpr int EV = 16 / sizeof(T);
+    const size_t nv = n / EV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        const Pack16<T> a = ((const Pack16<T>*)gy)[i], b = ((const Pack16<T>*)src)[i];
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o.v[e] = (T)((float)a.v[e] * dact_apply(mode, (float)b.v[e]));
+        ((Pack16<T>*)ga)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nv * EV; i < n; ++i) ga[i] = (T)((float)gy[i] * dact_apply(mode, (float)src[i]));
+}
+
+// y = act(x)
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, int act) {
+    constexpr int EV = 16 / sizeof(T);
+    const size_t nv = n / EV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        const Pack16<T> a = ((const Pack16<T>*)x)[i];
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o.v[e] = (T)act_apply(act, (float)a.v[e]);
+        ((Pack16<T>*)y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nv * EV; i < n; ++i) y[i] = (T)act_apply(act, (float)x[i]);
 }
 
 // out[m] += sum_rows g[row][m]   (bias gradient)
@@ -581,8 +609,20 @@ int ga_avgpool1d_bwd(const void* dy, void* dx, int dtype, int B, int L, int Lo, 
 
 int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, int mode, hipStream_t s) {
     if (!gy || !src || !ga) return GA_ERR_ARG;
-    DISPATCH_T(dtype, (act_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, n, mode)),
-               (act_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, n, mode)));
+    if (((uintptr_t)gy | (uintptr_t)src | (uintptr_t)ga) & 15) return GA_ERR_ALIGN;
+    const int grid = grid_for(n / 4 + 1, 256, 4096);
+    DISPATCH_T(dtype, (act_bwd_kernel<float><<<grid, 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, n, mode)),
+               (act_bwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, n, mode)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_act_fwd(const void* x, void* y, int dtype, size_t n, int act, hipStream_t s) {
+    if (!x || !y) return GA_ERR_ARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return GA_ERR_ALIGN;
+    const int grid = grid_for(n / 4 + 1, 256, 4096);
+    DISPATCH_T(dtype, (act_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, n, act)),
+               (act_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, act)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -230,11 +230,18 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         x_real_g = frozen_out[-B0:]
 
     if take_d_step:
-        x_real = x_real_d_all.detach().requires_grad_(float(stage_cfg.r1_gamma) > 0.0)
-        real_outs = discriminator(x_real)
-        fake_outs_d = discriminator(x_hat.detach())
-        loss_d = multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d)
         do_r1 = float(stage_cfg.r1_gamma) > 0.0 and (global_step % max(1, int(stage_cfg.r1_interval)) == 0)
+        if do_r1:
+            x_real = x_real_d_all.detach().requires_grad_(True)
+            real_outs = discriminator(x_real)
+            fake_outs_d = discriminator(x_hat.detach())
+        else:
+            # D acts on every batch item independently, so the real and fake passes (:423-424) run as ONE pass over
+            # the concatenated batch: twice the GEMM N per launch, half the launches, one weight-gradient pass.
+            both = discriminator(torch.cat([x_real_d_all.detach(), x_hat.detach()], dim=0))
+            real_outs = [(lg[:B0], [f[:B0] for f in fs]) for lg, fs in both]
+            fake_outs_d = [(lg[B0:], [f[B0:] for f in fs]) for lg, fs in both]
+        loss_d = multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d)
         opt_d.zero_grad(set_to_none=True)
         loss_d_total = loss_d.detach()
         if do_r1:

@@ -322,6 +322,12 @@ class ConvTrain(torch.autograd.Function):
         return gx, None, None, gw, gb, None, None
 
 
+def act_fwd(x: Tensor, act: int) -> Tensor:
+    y = torch.empty_like(x)
+    L.check(L.lib().ga_act_fwd(x.data_ptr(), y.data_ptr(), L.dt(x), x.numel(), act, L.stream()), "ga_act_fwd")
+    return y
+
+
 class ConvFrozen(torch.autograd.Function):
     """y = conv(pre_act(x)) + bias (+ res) with frozen weights (SEANet decoder): only dx is produced.
     dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
@@ -329,7 +335,12 @@ class ConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False):
         x = x.contiguous()
-        y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
+        if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16:
+            # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
+            # which cannot transform its operand in flight
+            y = conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, res=None if res is None else res.contiguous(), out_f32=out_f32)
+        else:
+            y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
         ctx.geom, ctx.pre_act = geom, pre_act
         ctx.x_dtype = x.dtype
         ctx.save_for_backward(x if pre_act else None, wp_d)
