@@ -9,6 +9,8 @@ int ga_conv_gemm_supported(const ConvParams& p);
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s);
 int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
+int ga_wgrad_gemm_supported(const WgradParams& p);
+int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s);
 int ga_thin_conv_supported(const ConvParams& p, int dtype);
 int ga_thin_conv_impl(const ConvParams& p, int dtype, hipStream_t s);
 int ga_thin_wgrad_supported(const WgradParams& p, int dtype);
@@ -62,10 +64,13 @@ int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {
     if (p.g_stride < 1 || p.LgTot < 1 || p.B > 65535) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
     const int thin = ga_thin_wgrad_supported(p, dtype);
-    if (thin && impl != GA_IMPL_MFMA) return ga_thin_wgrad_impl(p, p.dbias, dtype, thin, s);  // fuses the bias gradient
+    if (thin && impl != GA_IMPL_MFMA && impl != GA_IMPL_MFMA_WINDOW) return ga_thin_wgrad_impl(p, p.dbias, dtype, thin, s);  // fuses the bias gradient
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_wgrad_mfma_supported(p);
+    const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_wgrad_gemm_supported(p);
     int rc;
-    if (impl == GA_IMPL_MFMA) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
+    if (impl == GA_IMPL_MFMA_WINDOW) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
+    else if ((impl == GA_IMPL_MFMA || impl == GA_IMPL_AUTO) && can_gemm) rc = ga_wgrad_gemm_impl(p, s);
+    else if (impl == GA_IMPL_MFMA) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
     else if (impl == GA_IMPL_AUTO && can_mfma) rc = ga_wgrad_mfma_impl(p, s);
     else if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) rc = GA_ERR_ARG;
     else rc = ga_wgrad_direct_impl(p, dtype, s);

@@ -55,6 +55,9 @@ __device__ __forceinline__ float dact_apply(int m, float s) {
     }
 }
 
+// 16 zero bytes: the source of every padded / out-of-range piece of a direct-to-LDS load (one copy per translation unit)
+static __device__ __attribute__((aligned(16))) unsigned int ga_zero_page[4] = {0u, 0u, 0u, 0u};
+
 // The generalised NLC convolution / weight-gradient problem descriptors are part of the C ABI.
 typedef ga_conv_params ConvParams;
 typedef ga_wgrad_params WgradParams;

@@ -21,7 +21,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define GBK 64  // K elements per step
 
-__device__ __attribute__((aligned(16))) unsigned int ga_zero_page[4] = {0u, 0u, 0u, 0u};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;

@@ -21,6 +21,9 @@ __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v))
 template <typename WT> struct Mma;
 template <> struct Mma<bf16_t> {
     static constexpr int KSTEP = 32;
+    typedef bf16x8 V;
+    static __device__ __forceinline__ V load(const bf16_t* row, int k0, int kq) { return *(const bf16x8*)(row + k0 + 8 * kq); }
+    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
     // a_row / b_row: pointers to element k=0 of this lane's row (A) / column (B); lane group kq = lane >> 4
     static __device__ __forceinline__ f32x4 run(const bf16_t* a_row, const bf16_t* b_row, int k0, int kq, f32x4 acc) {
         const bf16x8 a = *(const bf16x8*)(a_row + k0 + 8 * kq);
@@ -30,6 +33,14 @@ template <> struct Mma<bf16_t> {
 };
 template <> struct Mma<float> {
     static constexpr int KSTEP = 16;
+    typedef float4 V;
+    static __device__ __forceinline__ V load(const float* row, int k0, int kq) { return *(const float4*)(row + k0 + 4 * kq); }
+    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
     static __device__ __forceinline__ f32x4 run(const float* a_row, const float* b_row, int k0, int kq, f32x4 acc) {
         const float4 a = *(const float4*)(a_row + k0 + 4 * kq);
         const float4 b = *(const float4*)(b_row + k0 + 4 * kq);
@@ -184,6 +195,244 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(ga_lstm_bwd_params p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Latency-shaped step kernels (compile-time H, up to NBT batch tiles of 16 per pass).  A step is one dependent
+// L2 round trip, so everything a lane needs is requested BEFORE anything is consumed: the epilogue's gate inputs
+// and cell state first, then every A/B fragment of the lane's K range (CH k-steps per burst, sized to the VGPR
+// budget), and only then the MFMAs.  All batch tiles share one pass over the weights.
+template <typename WT, int NK, int NBT>
+__device__ __forceinline__ void seg_mma(const WT* a_row, const WT* const (&b_row)[NBT], int kq, f32x4 (&acc)[NBT]) {
+    typedef typename Mma<WT>::V V;
+    constexpr int KS = Mma<WT>::KSTEP;
+    constexpr int CAP = (sizeof(WT) == 2 ? 32 : 24) / (1 + NBT);
+    constexpr int CH = NK < CAP ? NK : CAP;
+    for (int s0 = 0; s0 < NK; s0 += CH) {
+        V a[CH], b[NBT][CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int sk = (s0 + s < NK ? s0 + s : NK - 1) * KS;
+            a[s] = Mma<WT>::load(a_row, sk, kq);
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) b[i][s] = Mma<WT>::load(b_row[i], sk, kq);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every load of the burst is issued before the first MFMA waits on one
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+            if (s0 + s < NK) {
+#pragma unroll
+                for (int i = 0; i < NBT; ++i) acc[i] = Mma<WT>::mma(a[s], b[i][s], acc[i]);
+            }
+    }
+}
+
+template <typename WT, typename AT, int H, int NBT>
+__global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, int s, int b_base) {
+    __shared__ float red[4][NBT][16][17];
+    constexpr int KS = Mma<WT>::KSTEP;
+    const int layer = blockIdx.y;
+    const int t = layer == 0 ? s : s - 1;
+    if (t < 0 || t >= p.T) return;
+    const int u0 = blockIdx.x * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rc = lane & 15, kq = lane >> 4;
+    const int arow = (rc >> 2) * H + u0 + (rc & 3);
+    const WT* __restrict__ h1 = (const WT*)p.h1;
+    const WT* __restrict__ h2 = (const WT*)p.h2;
+    float* cst = layer == 0 ? p.c1 : p.c2;
+    float* gsave = layer == 0 ? p.gates1 : p.gates2;
+    float* csave = layer == 0 ? p.cs1 : p.cs2;
+    WT* hout = layer == 0 ? (WT*)p.h1 : (WT*)p.h2;
+
+    // epilogue role (tile, unit, batch column) and its inputs, requested first
+    const int e_tile = tid >> 6, e_uu = (tid >> 4) & 3, e_bb = tid & 15;
+    const int e_b = b_base + e_tile * 16 + e_bb, e_u = u0 + e_uu;
+    const bool e_on = e_tile < NBT && e_b < p.B;
+    // (unconditional raw loads from clamped addresses: a branch, a conversion or a per-element select here would make
+    // the compiler wait for each load in turn)
+    const int e_bl = e_b < p.B ? e_b : p.B - 1;
+    const AT* xgp = (const AT*)p.xg1 + ((size_t)e_bl * p.T + t) * 4 * H + e_u;
+    const float* bsp = p.bias2 + e_u;
+    const AT xg0 = xgp[0], xg1v = xgp[H], xg2 = xgp[2 * H], xg3 = xgp[3 * H];
+    const float bs0 = bsp[0], bs1 = bsp[H], bs2 = bsp[2 * H], bs3 = bsp[3 * H];
+    const AT xs_raw = ((const AT*)p.x_in)[((size_t)e_bl * p.T + t) * H + e_u];
+    const float c_prev = cst[(size_t)e_bl * H + e_u];
+
+    f32x4 acc[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int bld[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+        const int bcol = b_base + i * 16 + rc;
+        bld[i] = bcol < p.B ? bcol : p.B - 1;  // clamp loads; results of padded columns are discarded
+    }
+    if (layer == 0) {
+        if (t > 0) {
+            constexpr int NK = H / KS / 4;
+            const WT* a = (const WT*)p.w1 + (size_t)arow * H + wid * (H / 4);
+            const WT* b[NBT];
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) b[i] = h1 + ((size_t)bld[i] * p.T + (t - 1)) * H + wid * (H / 4);
+            seg_mma<WT, NK, NBT>(a, b, kq, acc);
+        }
+    } else {
+        // combined K = [h1_t | h2_{t-1}]: waves 0,1 take the h1 half, waves 2,3 the h2 half (absent at t = 0)
+        constexpr int NK = 2 * H / KS / 4;
+        const int koff = wid * (H / 2);
+        if (koff < H || t > 0) {
+            const WT* a = (const WT*)p.w2 + (size_t)arow * 2 * H + koff;
+            const WT* b[NBT];
+#pragma unroll
+            for (int i = 0; i < NBT; ++i)
+                b[i] = koff < H ? h1 + ((size_t)bld[i] * p.T + t) * H + koff : h2 + ((size_t)bld[i] * p.T + (t - 1)) * H + (koff - H);
+            seg_mma<WT, NK, NBT>(a, b, kq, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wid][i][kq * 4 + j][rc] = acc[i][j];  // D: row = 4*kq + j, col = rc
+    __syncthreads();
+    if (e_on) {
+        float pre[4];
+        const float x_skip = (float)xs_raw;
+        pre[0] = layer == 0 ? (float)xg0 : bs0;
+        pre[1] = layer == 0 ? (float)xg1v : bs1;
+        pre[2] = layer == 0 ? (float)xg2 : bs2;
+        pre[3] = layer == 0 ? (float)xg3 : bs3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = g * 4 + e_uu;
+            pre[g] += red[0][e_tile][r][e_bb] + red[1][e_tile][r][e_bb] + red[2][e_tile][r][e_bb] + red[3][e_tile][r][e_bb];
+        }
+        const float ig = sigm(pre[0]), fg = sigm(pre[1]), gg = tanhf(pre[2]), og = sigm(pre[3]);
+        const float c = fg * c_prev + ig * gg;
+        cst[(size_t)e_b * H + e_u] = c;
+        const float h = og * tanhf(c);
+        const size_t hi = ((size_t)e_b * p.T + t) * H + e_u;
+        hout[hi] = (WT)h;
+        if (gsave) {
+            float* gs = gsave + ((size_t)e_b * p.T + t) * 4 * H + e_u;
+            gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+            csave[hi] = c;
+        }
+        if (layer == 1) ((AT*)p.y)[hi] = (AT)(h + x_skip);
+    }
+}
+
+template <typename WT, typename AT, int H, int NBT>
+__global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p, int s, int b_base) {
+    __shared__ float red[4][NBT][16][17];
+    constexpr int KS = Mma<WT>::KSTEP;
+    constexpr int NK = 4 * H / KS / 4;
+    const int layer = blockIdx.y;  // 0: layer 2 (leads), 1: layer 1
+    const int t = layer == 0 ? p.T - 1 - s : p.T - s;
+    if (t < 0 || t >= p.T) return;
+    const int u0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rc = lane & 15, kq = lane >> 4;
+    const WT* __restrict__ dg1 = (const WT*)p.dg1;
+    const WT* __restrict__ dg2 = (const WT*)p.dg2;
+    const float* gates = layer == 0 ? p.gates2 : p.gates1;
+    const float* cs = layer == 0 ? p.cs2 : p.cs1;
+    float* dcs = layer == 0 ? p.dc2 : p.dc1;
+    WT* dgout = layer == 0 ? (WT*)p.dg2 : (WT*)p.dg1;
+
+    // epilogue role: 256 threads = 16 units x 16 batch columns, looped over the NBT tiles; inputs requested first
+    const int e_uu = tid >> 4, e_bb = tid & 15, e_u = u0 + e_uu;
+    float e_ig[NBT], e_fg[NBT], e_gg[NBT], e_og[NBT], e_c[NBT], e_cp[NBT], e_dc[NBT];
+    AT e_dyr[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {  // unconditional loads from clamped addresses (see the forward kernel)
+        const int b = b_base + i * 16 + e_bb;
+        const int bl = b < p.B ? b : p.B - 1;
+        const size_t hi = ((size_t)bl * p.T + t) * H + e_u;
+        const float* gs = gates + ((size_t)bl * p.T + t) * 4 * H + e_u;
+        e_ig[i] = gs[0]; e_fg[i] = gs[H]; e_gg[i] = gs[2 * H]; e_og[i] = gs[3 * H];
+        e_c[i] = cs[hi];
+        e_cp[i] = cs[t > 0 ? hi - H : hi];
+        e_dc[i] = dcs[(size_t)bl * H + e_u];
+        e_dyr[i] = ((const AT*)p.dy)[hi];
+    }
+
+    f32x4 acc[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int bld[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+        const int bcol = b_base + i * 16 + rc;
+        bld[i] = bcol < p.B ? bcol : p.B - 1;
+    }
+    const int koff = wid * H;  // this wave's quarter of K = 4H
+    const WT* b[NBT];
+    if (layer == 0) {
+        // dh2_t[u] = dy_t[u] + sum_k dg2_{t+1}[k] * W_hh_l1[k][u]       (w2t row H + u)
+        if (t + 1 < p.T) {
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) b[i] = dg2 + ((size_t)bld[i] * p.T + (t + 1)) * 4 * H + koff;
+            seg_mma<WT, NK, NBT>((const WT*)p.w2t + (size_t)(H + u0 + rc) * 4 * H + koff, b, kq, acc);
+        }
+    } else {
+        // dh1_t[u] = sum_k dg2_t[k] * W_ih_l1[k][u] + sum_k dg1_{t+1}[k] * W_hh_l0[k][u]
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) b[i] = dg2 + ((size_t)bld[i] * p.T + t) * 4 * H + koff;
+        seg_mma<WT, NK, NBT>((const WT*)p.w2t + (size_t)(u0 + rc) * 4 * H + koff, b, kq, acc);
+        if (t + 1 < p.T) {
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) b[i] = dg1 + ((size_t)bld[i] * p.T + (t + 1)) * 4 * H + koff;
+            seg_mma<WT, NK, NBT>((const WT*)p.w1t + (size_t)(u0 + rc) * 4 * H + koff, b, kq, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wid][i][kq * 4 + j][rc] = acc[i][j];  // row = unit, col = batch
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+        const int bq = b_base + i * 16 + e_bb;
+        if (bq < p.B) {
+            const float dh = red[0][i][e_uu][e_bb] + red[1][i][e_uu][e_bb] + red[2][i][e_uu][e_bb] + red[3][i][e_uu][e_bb] + (layer == 0 ? (float)e_dyr[i] : 0.f);
+            const float cprev = t > 0 ? e_cp[i] : 0.f;
+            const float ig = e_ig[i], fg = e_fg[i], gg = e_gg[i], og = e_og[i];
+            const float tc = tanhf(e_c[i]);
+            const float dc = e_dc[i] + dh * og * (1.f - tc * tc);
+            dcs[(size_t)bq * H + e_u] = dc * fg;
+            WT* o = dgout + ((size_t)bq * p.T + t) * 4 * H + e_u;
+            o[0] = (WT)(dc * gg * ig * (1.f - ig));
+            o[H] = (WT)(dc * cprev * fg * (1.f - fg));
+            o[2 * H] = (WT)(dc * ig * (1.f - gg * gg));
+            o[3 * H] = (WT)(dh * tc * og * (1.f - og));
+        }
+    }
+}
+
+template <typename WT, typename AT, int H>
+static void launch_fwd_fast(const ga_lstm_params& p, int st, hipStream_t s) {
+    const dim3 grid(H / 4, 2);
+    for (int b0 = 0; b0 < p.B; b0 += 64) {
+        const int nbt = (((p.B - b0) < 64 ? (p.B - b0) : 64) + 15) / 16;
+        switch (nbt) {
+            case 1: lstm_fwd_fast_kernel<WT, AT, H, 1><<<grid, 256, 0, s>>>(p, st, b0); break;
+            case 2: lstm_fwd_fast_kernel<WT, AT, H, 2><<<grid, 256, 0, s>>>(p, st, b0); break;
+            case 3: lstm_fwd_fast_kernel<WT, AT, H, 3><<<grid, 256, 0, s>>>(p, st, b0); break;
+            default: lstm_fwd_fast_kernel<WT, AT, H, 4><<<grid, 256, 0, s>>>(p, st, b0); break;
+        }
+    }
+}
+
+template <typename WT, typename AT, int H>
+static void launch_bwd_fast(const ga_lstm_bwd_params& p, int st, hipStream_t s) {
+    const dim3 grid(H / 16, 2);
+    for (int b0 = 0; b0 < p.B; b0 += 32) {
+        const int nbt = (((p.B - b0) < 32 ? (p.B - b0) : 32) + 15) / 16;
+        if (nbt == 1) lstm_bwd_fast_kernel<WT, AT, H, 1><<<grid, 256, 0, s>>>(p, st, b0);
+        else lstm_bwd_fast_kernel<WT, AT, H, 2><<<grid, 256, 0, s>>>(p, st, b0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -196,7 +445,11 @@ int ga_lstm_fwd(const ga_lstm_params* hp, hipStream_t s) {
     if (((uintptr_t)p.w1 | (uintptr_t)p.w2 | (uintptr_t)p.h1 | (uintptr_t)p.h2) & 15) return GA_ERR_ALIGN;
     const dim3 grid(p.H / 4, 2);
     for (int st = 0; st <= p.T; ++st) {
-        if (p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
+        if (p.H == 512 && p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
+            launch_fwd_fast<bf16_t, bf16_t, 512>(p, st, s);
+        else if (p.H == 512 && p.w_dtype == GA_DTYPE_F32 && p.act_dtype == GA_DTYPE_F32)
+            launch_fwd_fast<float, float, 512>(p, st, s);
+        else if (p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
             lstm_fwd_step_kernel<bf16_t, bf16_t><<<grid, 256, 0, s>>>(p, st);
         else if (p.w_dtype == GA_DTYPE_F32 && p.act_dtype == GA_DTYPE_F32)
             lstm_fwd_step_kernel<float, float><<<grid, 256, 0, s>>>(p, st);
@@ -215,7 +468,11 @@ int ga_lstm_bwd(const ga_lstm_bwd_params* hp, hipStream_t s) {
     if (((uintptr_t)p.w1t | (uintptr_t)p.w2t | (uintptr_t)p.dg1 | (uintptr_t)p.dg2) & 15) return GA_ERR_ALIGN;
     const dim3 grid(p.H / 16, 2);
     for (int st = 0; st <= p.T; ++st) {
-        if (p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
+        if (p.H == 512 && p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
+            launch_bwd_fast<bf16_t, bf16_t, 512>(p, st, s);
+        else if (p.H == 512 && p.w_dtype == GA_DTYPE_F32 && p.act_dtype == GA_DTYPE_F32)
+            launch_bwd_fast<float, float, 512>(p, st, s);
+        else if (p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
             lstm_bwd_step_kernel<bf16_t, bf16_t><<<grid, 256, 0, s>>>(p, st);
         else if (p.w_dtype == GA_DTYPE_F32 && p.act_dtype == GA_DTYPE_F32)
             lstm_bwd_step_kernel<float, float><<<grid, 256, 0, s>>>(p, st);

@@ -1,0 +1,197 @@
+// bf16 MFMA weight-gradient kernel, "gathered GEMM" form (gfx950):
+//
+//   dW[m][k] += sum_n G[n][m] * X[n][k]      n = (batch item, output step) flattened, k = (tap j, channel c)
+//
+// Both operands have the REDUCTION index n on the slow memory axis (channels-last), so both LDS tiles stay
+// row-major [n][channel]: rows of G are contiguous in m, and the im2col row of X for step n is gathered piece by
+// piece (8 channels = 16 bytes) exactly as in conv_gemm.hip.  Every piece goes global -> LDS with
+// global_load_lds_dwordx4 (no register staging); MFMA fragments come out of LDS with the CDNA4 transposing read
+// ds_read_b64_tr_b16, which hands each lane 4 consecutive n of its column.
+//
+//   block tile 128 (m) x 128 (k) of dW, 4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16
+//   reduction step 64 rows; two LDS buffers per operand ([64][128] bf16 = 16 KiB each), next step in flight
+//   LDS rows are 256 B; the 64-byte quarter q of row r is stored at quarter q ^ (r & 3), so the four rows one
+//   transposing read touches land on different bank quarters (conflict-free); the XOR sits on the SOURCE piece.
+//   The reduction range is split over gridDim.y; partial tiles are added with fp32 atomics (128-byte row segments).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void wg_glds16(uintptr_t src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ uintptr_t wg_sel(bool ok, uintptr_t a, uintptr_t z) {
+    return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
+}
+// fragment of 32 columns x 16 reduction rows: two transposing reads, rows q and q + 4 of this lane's 8-row half
+__device__ __forceinline__ bf16x8 wg_tr_frag(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p1);
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define WGG_RK 64    // reduction rows per step
+#define WGG_TILE (WGG_RK * 256)  // bytes of one operand tile
+
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const Al = smem;                 // [2][64][256 B]  G rows
+    char* const Bl = smem + 2 * WGG_TILE;  // [2][64][256 B]  gathered X rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int kt = blockIdx.x % ktiles, mt = blockIdx.x / ktiles;
+    const int mbase = mt * 128, kbase = kt * 128;
+    const int S = p.in_stride, Cin = p.Cin;
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+
+    const int s_begin = blockIdx.y * steps_per_split;
+    int s_end = s_begin + steps_per_split;
+    if (s_end > nsteps_total) s_end = nsteps_total;
+    if (s_begin >= s_end) return;
+
+    // staging role: instruction i covers rows i*16 + wid*4 + (lane>>4); this lane's physical 16-byte slot lane&15
+    const int prow = lane >> 4;
+    const int lpiece = (lane & 15) ^ (prow << 2);  // logical piece held by this lane's slot (row & 3 == prow)
+    const int am = mbase + lpiece * 8;
+    const bool a_ok = am < p.M;
+    const int bk = kbase + lpiece * 8;
+    const bool b_ok = bk < Ktot;
+    const int bj = b_ok ? bk / Cin : 0;
+    const int bc = b_ok ? bk - bj * Cin : 0;
+    const int bdR = bj * p.tap_step + p.off0;
+    // per-row running (b, t) for the 4 rows this lane stages
+    int rb[4], rt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long n = (long)s_begin * WGG_RK + i * 16 + wid * 4 + prow;
+        rb[i] = (int)(n / p.Lout);
+        rt[i] = (int)(n - (long)rb[i] * p.Lout);
+    }
+    const bf16_t* __restrict__ g = (const bf16_t*)p.g;
+    const bf16_t* __restrict__ x = (const bf16_t*)p.x;
+
+    auto issue = [&](int buf) {
+        char* const ab = Al + buf * WGG_TILE + wid * 1024;
+        char* const bb = Bl + buf * WGG_TILE + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool n_ok = rb[i] < p.B;
+            const uintptr_t asrc = (uintptr_t)(g + ((size_t)rb[i] * p.LgTot + rt[i]) * p.M + am);
+            wg_glds16(wg_sel(n_ok && a_ok, asrc, zero), ab + i * 4096);
+            const int R = rt[i] * S + bdR;
+            const uintptr_t bsrc = (uintptr_t)(x + ((size_t)rb[i] * p.Lin + R) * Cin + bc);
+            wg_glds16(wg_sel(n_ok && b_ok && R >= 0 && R < p.Lin, bsrc, zero), bb + i * 4096);
+            // advance this row by one reduction step
+            rt[i] += WGG_RK;
+            while (rt[i] >= p.Lout) { rt[i] -= p.Lout; ++rb[i]; }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    // transposed-read addressing: row = kk*16 + 8h + q (+4), columns 16*(g4&1) + 4*pp .. +3 of the wave's 32-column
+    // fragment; element column e -> logical piece e>>3, byte (e&7)*2; physical piece = logical ^ ((row&3)<<2), row&3 == q
+    const int ecolA[2] = {wm * 64 + 16 * (g4 & 1) + 4 * pp, wm * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
+    const int ecolB[2] = {wn * 64 + 16 * (g4 & 1) + 4 * pp, wn * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
+    int offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = ((((ecolA[i] >> 3) ^ (q << 2)) << 4) | ((ecolA[i] & 7) << 1)) + (8 * h + q) * 256;
+        offB[i] = ((((ecolB[i] >> 3) ^ (q << 2)) << 4) | ((ecolB[i] & 7) << 1)) + (8 * h + q) * 256;
+    }
+    const bool wave_active = (mbase + wm * 64) < p.M && (kbase + wn * 64) < Ktot;
+
+    issue(0);
+    for (int st = s_begin; st < s_end; ++st) {
+        const int buf = (st - s_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < s_end) issue(buf ^ 1);
+        if (wave_active) {
+            const char* Ab = Al + buf * WGG_TILE;
+            const char* Bb = Bl + buf * WGG_TILE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = wg_tr_frag(Ab + kk * 4096 + offA[mi], Ab + kk * 4096 + offA[mi] + 1024);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) b[ni] = wg_tr_frag(Bb + kk * 4096 + offB[ni], Bb + kk * 4096 + offB[ni] + 1024);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!wave_active) return;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int k = kbase + wn * 64 + ni * 32 + r;
+        if (k >= Ktot) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = mbase + wm * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < p.M) atomicAdd(&p.dw[(size_t)m * Ktot + k], acc[mi][ni][i]);
+            }
+        }
+    }
+}
+
+int ga_wgrad_gemm_supported(const WgradParams& p) {
+    if (p.M % 8 || p.Cin % 8 || p.M < 32 || p.Cin < 8 || p.J < 1) return 0;
+    if (p.g_stride != 1 || p.g_phase != 0 || p.tap_step < 0) return 0;
+    if (((uintptr_t)p.g | (uintptr_t)p.x | (uintptr_t)p.dw) & 15) return 0;
+    if ((long)p.B * p.Lout < 256 || (long)p.B * p.Lout > (1L << 30) || (long)p.J * p.Cin > (1L << 24)) return 0;
+    return 1;
+}
+
+int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s) {
+    if (!ga_wgrad_gemm_supported(p)) return GA_ERR_ARG;
+    const int Ktot = p.J * p.Cin;
+    const long Ntot = (long)p.B * p.Lout;
+    const int mtiles = (p.M + 127) / 128, ktiles = (Ktot + 127) / 128;
+    const long base = (long)mtiles * ktiles;
+    const long nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
+    long splits = (1024 + base - 1) / base;        // aim for ~1k workgroups (4 per CU)
+    const long max_splits = (nsteps + 7) / 8;       // at least 8 steps (512 rows) per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int sps = (int)((nsteps + splits - 1) / splits);
+    splits = (nsteps + sps - 1) / sps;
+    const size_t lds = 4 * WGG_TILE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    wgrad_gemm_kernel<<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}

@@ -166,11 +166,13 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
 
 
 def test_mfma_weight_gradient_matches_direct():
-    """bf16 weight gradient: transposed-LDS-read MFMA kernel against the direct kernel on the same bf16 operands."""
+    """bf16 weight gradient: the gathered-GEMM MFMA kernel (direct-to-LDS loads, transposing LDS reads) and the older
+    window MFMA kernel against the direct kernel on the same bf16 operands (ragged M / K / reduction tiles included)."""
     torch.manual_seed(9)
     for g, Ln, B in ((ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 2), (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 1875, 2),
                      (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 3), (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 375, 3),
-                     (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 938, 2)):
+                     (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 938, 2), (ConvGeom("conv", 16, 48, 5, 2, 2, 1), 301, 3),
+                     (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 37, 9), (ConvGeom("conv", 24, 40, 7, 1, 3, 2), 1000, 1)):
         x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
         ga = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
         outs = []
@@ -181,6 +183,12 @@ def test_mfma_weight_gradient_matches_direct():
             finally:
                 ops.set_conv_impl(L.IMPL_AUTO)
         close(outs[0], outs[1].cpu(), 2e-3, f"wgrad {g}")
+        if g.cin >= 32 and g.cin % 8 == 0 and g.cout % 8 == 0 and B * g.out_len(Ln) >= 256:
+            ops.set_conv_impl(L.IMPL_MFMA_WINDOW)
+            try:
+                close(ops.conv_wgrad(g, ga, x), outs[1].cpu(), 2e-3, f"window wgrad {g}")
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
