@@ -47,7 +47,7 @@ class WgradParams(C.Structure):
 
 class LstmParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "bias2", "xg1", "x_in", "y", "h1", "h2", "c1", "c2", "gates1", "gates2",
-                                          "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype")]
+                                          "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype", "B_save")]
 
 
 class LstmBwdParams(C.Structure):

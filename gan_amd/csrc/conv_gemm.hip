@@ -14,6 +14,7 @@
 //   16-byte slot s of row r holds logical piece s ^ ((r>>1)&7): with that XOR the ds_read_b128 of a 32-row
 //   fragment is bank-conflict-free (cdna_hip_programming.md 5.5 T2; the XOR is applied on the SOURCE address).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -211,8 +212,15 @@ int ga_conv_gemm_supported(const ConvParams& p) {
     return 1;
 }
 
-static int g_gemm_nbuf = 2;
-extern "C" void ga_debug_set_gemm_nbuf(int n) { g_gemm_nbuf = n == 1 ? 1 : 2; }
+// GA_GEMM_NBUF=1|2 in the environment pins the LDS buffering of the 128x128 configuration (tuning aid); default: by grid size
+static int gemm_nbuf_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_NBUF");
+        v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+    }
+    return v;
+}
 
 template <int WM, int WN, int NBUF>
 static int launch_gemm(const ConvParams& p, hipStream_t s) {
@@ -239,6 +247,11 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
-    if (g_gemm_nbuf == 1) return p.M <= 64 ? launch_gemm<1, 4, 1>(p, s) : launch_gemm<2, 2, 1>(p, s);
-    return p.M <= 64 ? launch_gemm<1, 4, 2>(p, s) : launch_gemm<2, 2, 2>(p, s);
+    if (p.M <= 64) return launch_gemm<1, 4, 2>(p, s);
+    // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
+    // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
+    const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase;
+    int nbuf = gemm_nbuf_override();
+    if (!nbuf) nbuf = blocks >= 600 ? 1 : 2;
+    return nbuf == 1 ? launch_gemm<2, 2, 1>(p, s) : launch_gemm<2, 2, 2>(p, s);
 }

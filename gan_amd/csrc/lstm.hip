@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(ga_lstm_params p, in
                 const float h = og * tanhf(c);
                 const size_t hi = ((size_t)b * p.T + t) * H + u;
                 hout[hi] = (WT)h;
-                if (gsave) {
+                if (gsave && (p.B_save <= 0 || b < p.B_save)) {
                     float* gs = gsave + ((size_t)b * p.T + t) * 4 * H + u;
                     gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
                     csave[hi] = c;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, in
         const float h = og * tanhf(c);
         const size_t hi = ((size_t)e_b * p.T + t) * H + e_u;
         hout[hi] = (WT)h;
-        if (gsave) {
+        if (gsave && (p.B_save <= 0 || e_b < p.B_save)) {
             float* gs = gsave + ((size_t)e_b * p.T + t) * 4 * H + e_u;
             gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
             csave[hi] = c;

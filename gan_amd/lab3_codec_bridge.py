@@ -132,12 +132,35 @@ class SeanetDecoder(nn.Module):
         wp_f, wp_d = self._pack(name, layer, dtype)
         return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act, out_f32)
 
-    def forward(self, q_bct: torch.Tensor) -> torch.Tensor:
-        """q [B, 128, T] -> wav [B, 1, T*prod(ratios)]"""
+    def forward(self, q_bct: torch.Tensor, n_grad: Optional[int] = None):
+        """q [B, 128, T] -> wav [B, 1, T*prod(ratios)].
+        With n_grad, the batch is [n_grad items that need d(wav)/d(q) ; frozen items]: the first conv and the
+        (launch-bound) LSTM run once over the whole batch, the convolutional tail runs per part, and the result is the
+        pair (wav of the gradient part, wav of the frozen part)."""
         L.require_cuda(q_bct)
         dtype = _act_dtype(self.precision)
         h = q_bct.permute(0, 2, 1).to(dtype).contiguous()  # NLC
-        for kind, name in self._plan:
+        if n_grad is not None and not self.use_library_lstm and 0 < n_grad < h.shape[0]:
+            h = self._conv("0", getattr(self.layers, "0"), h, dtype)
+            key = ("lstm", dtype)
+            if key not in self._packs:
+                self._packs[key] = ops.prepare_lstm_weights(getattr(self.layers, "1").lstm, dtype)
+            h = ops.LstmSkip.apply(h, self._packs[key], int(n_grad))
+            out_g = self._tail(h[:n_grad], dtype, self._plan[2:])
+            with torch.no_grad():
+                out_f = self._tail(h[n_grad:].detach(), dtype, self._plan[2:])
+            return out_g, out_f
+        if n_grad is not None:
+            if n_grad >= h.shape[0]:
+                return self._tail(h, dtype, self._plan), None
+            out_g = self._tail(h[:n_grad], dtype, self._plan)
+            with torch.no_grad():
+                out_f = self._tail(h[n_grad:].detach(), dtype, self._plan)
+            return out_g, out_f
+        return self._tail(h, dtype, self._plan)
+
+    def _tail(self, h: torch.Tensor, dtype, plan) -> torch.Tensor:
+        for kind, name in plan:
             layer = getattr(self.layers, name)
             if kind == "conv":
                 h = self._conv(name, layer, h, dtype)
@@ -195,6 +218,14 @@ class FrozenEncodec:
 
     def decode_embeddings(self, q_emb_b_c_t: torch.Tensor) -> torch.Tensor:
         return self.decoder(q_emb_b_c_t.to(self.device))
+
+    def decode_embeddings_mixed(self, q_grad_b_c_t: torch.Tensor, q_frozen_b_c_t: torch.Tensor):
+        """(decode_embeddings(q_grad), decode_embeddings(q_frozen) without gradient) as one pass through the shared,
+        launch-bound front of the decoder (first conv + LSTM); not in the reference, which makes four separate calls
+        (lab3_codec_train.py:413,415,422,458)."""
+        n = int(q_grad_b_c_t.shape[0])
+        q = torch.cat([q_grad_b_c_t, q_frozen_b_c_t.detach().to(q_grad_b_c_t.dtype)], dim=0)
+        return self.decoder(q.to(self.device), n_grad=n)
 
     def expected_num_frames(self) -> int:
         return int(round(float(self.cfg.chunk_seconds) * float(self.cfg.frame_rate)))

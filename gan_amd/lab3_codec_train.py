@@ -216,15 +216,19 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     out: Dict[str, torch.Tensor] = {}
     q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
                       style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
-    x_hat = codec.decode_embeddings(q_hat)
     take_d_step = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
     # The reference decodes q_src, q_real_tgt and q_real_tgt_g in three separate no-grad calls (:415,422,458).  The
     # decoder is frozen and acts on every batch item independently, so one batched call gives the same waveforms with a
     # third of the (launch-bound) LSTM steps.
     B0 = int(q_src.shape[0])
+    frozen_in = torch.cat([q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g], dim=0)
+    if hasattr(codec, "decode_embeddings_mixed"):
+        x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, frozen_in)
+    else:
+        x_hat = codec.decode_embeddings(q_hat)
+        with torch.no_grad():
+            frozen_out = codec.decode_embeddings(frozen_in)
     with torch.no_grad():
-        frozen_in = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
-        frozen_out = codec.decode_embeddings(torch.cat(frozen_in, dim=0))
         x_src = frozen_out[:B0]
         x_real_d_all = frozen_out[B0:2 * B0] if take_d_step else None
         x_real_g = frozen_out[-B0:]

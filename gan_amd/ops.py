@@ -179,7 +179,10 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
             q = _new_params()
             _fill(q, B=B, Lin=gy.shape[1], Cin=g.cout, M=g.cin, Lout=P, LoutTot=lin, J=g.k, in_stride=-1,
                   tap_step=g.dilation, off0=0, t0=1, accumulate=1, dact_mode=dact_mode)
-            _launch_conv(q, gy, wp_d, dx, dact_src=dact_src, impl=L.IMPL_DIRECT)
+            # the gathered-GEMM kernel takes any row stride (bf16); otherwise the direct kernel
+            kid = L.lib().ga_conv_kernel_id(C.byref(q), L.dt(gy), L.IMPL_MFMA) if _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) else -1
+            fix_impl = L.IMPL_MFMA if kid in (L.KERNEL_GEMM_64x256, L.KERNEL_GEMM_128x128) else L.IMPL_DIRECT
+            _launch_conv(q, gy, wp_d, dx, dact_src=dact_src, impl=fix_impl)
     return dx
 
 
@@ -627,10 +630,14 @@ class LstmSkip(torch.autograd.Function):
     `w` is the dict prepared by prepare_lstm_weights (frozen, cached by the decoder)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, n_grad: Optional[int] = None):
+        """n_grad: only the first n_grad batch items take part in the backward pass (the rest of the batch rides along
+        for the frozen, no-gradient decodes: one chain of step launches instead of two)."""
         L.require_cuda(x)
         x = x.contiguous()
         B, T, H = x.shape
+        Bg = B if n_grad is None else int(n_grad)
+        assert 0 < Bg <= B
         dtype = x.dtype
         wd = w["dtype"]
         assert wd == dtype, "LSTM weights must be prepared in the activation dtype"
@@ -642,27 +649,29 @@ class LstmSkip(torch.autograd.Function):
         h1 = torch.empty((B, T, H), device=dev, dtype=dtype)
         h2 = torch.empty((B, T, H), device=dev, dtype=dtype)
         c = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
-        gates = torch.empty((2, B, T, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
-        cs = torch.empty((2, B, T, H), device=dev, dtype=torch.float32) if need_grad else None
+        gates = torch.empty((2, Bg, T, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
+        cs = torch.empty((2, Bg, T, H), device=dev, dtype=torch.float32) if need_grad else None
         p = L.LstmParams()
         _fill(p, w1=w["hh0"].data_ptr(), w2=w["cat1"].data_ptr(), bias2=w["bias2"].data_ptr(), xg1=xg1.data_ptr(),
               x_in=x.data_ptr(), y=y.data_ptr(), h1=h1.data_ptr(), h2=h2.data_ptr(), c1=c[0].data_ptr(), c2=c[1].data_ptr(),
               gates1=L.ptr(gates[0]) if need_grad else 0, gates2=L.ptr(gates[1]) if need_grad else 0,
               cs1=L.ptr(cs[0]) if need_grad else 0, cs2=L.ptr(cs[1]) if need_grad else 0, B=B, T=T, H=H,
-              act_dtype=L.dt(x), w_dtype=L.dt(h1))
+              act_dtype=L.dt(x), w_dtype=L.dt(h1), B_save=Bg)
         L.check(L.lib().ga_lstm_fwd(C.byref(p), L.stream()), "ga_lstm_fwd")
         if need_grad:
             ctx.save_for_backward(gates, cs)
         ctx.w = w
         ctx.shape = (B, T, H)
+        ctx.Bg = Bg
         return y
 
     @staticmethod
     def backward(ctx, dy):
         gates, cs = ctx.saved_tensors
         w = ctx.w
-        B, T, H = ctx.shape
-        dy = dy.contiguous()
+        Bfull, T, H = ctx.shape
+        B = ctx.Bg
+        dy = dy[:B].contiguous()
         dev, dtype = dy.device, dy.dtype
         dg = torch.empty((2, B, T, 4 * H), device=dev, dtype=dtype)
         dc = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
@@ -672,7 +681,9 @@ class LstmSkip(torch.autograd.Function):
               dc1=dc[0].data_ptr(), dc2=dc[1].data_ptr(), B=B, T=T, H=H, act_dtype=L.dt(dy), w_dtype=L.dt(dg))
         L.check(L.lib().ga_lstm_bwd(C.byref(p), L.stream()), "ga_lstm_bwd")
         dx = conv_dgrad(w["geom_ih0"], dg[0], w["ih0_d"], T, res=dy)  # dg1 @ W_ih_l0 + dy (skip path)
-        return dx, None
+        if B < Bfull:
+            dx = torch.cat([dx, torch.zeros((Bfull - B, T, H), device=dev, dtype=dtype)], dim=0)
+        return dx, None, None
 
 
 def prepare_lstm_weights(lstm: torch.nn.LSTM, dtype: torch.dtype) -> dict:

@@ -218,6 +218,7 @@ typedef struct ga_lstm_params {
     float* gates1; float* gates2; /* [B][T][4H] or NULL */
     float* cs1; float* cs2;       /* [B][T][H] or NULL */
     int B, T, H, act_dtype, w_dtype;
+    int B_save; /* gates / cell states are recorded for batch items [0, B_save) only; <= 0 means all B */
 } ga_lstm_params;
 int ga_lstm_fwd(const ga_lstm_params* h_params, ga_stream_t stream);
 /* backward w.r.t. the input only (weights are frozen): fills dg1 = d(loss)/d(gate pre-activations of layer 1) for all

@@ -22,9 +22,8 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-nbuf = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-L.lib().ga_debug_set_gemm_nbuf(nbuf)
-print(f"B={B} nbuf={nbuf}")
+import os
+print(f"B={B} nbuf={os.environ.get('GA_GEMM_NBUF')}")
 for name, g, Ln in cases:
     x = torch.randn(B, Ln, g.cin, device="cuda").bfloat16()
     d0, d1, k = g.wdims

@@ -209,3 +209,25 @@ def test_bf16_iteration_tracks_fp32_oracle():
     for k in ("loss_g", "loss_d", "loss_adv", "loss_fm", "loss_lat_l1", "loss_lat_cont", "loss_mrstft"):
         assert float(out[k]) == pytest.approx(float(want[k]), rel=3e-2, abs=3e-3), k
     assert float(out["d_grad_norm"]) == pytest.approx(want["d_grad_norm"], rel=0.1)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_mixed_decode_equals_separate_decodes(precision):
+    """decode_embeddings_mixed (first conv + LSTM once over [gradient part ; frozen part]) gives the waveforms and the
+    input gradient of two separate decode_embeddings calls."""
+    g_sd, d_sd, dec_sd = O.fresh_state()
+    G, D, codec = build_gpu_models(g_sd, d_sd, dec_sd, precision)
+    torch.manual_seed(5)
+    qg = (0.5 * torch.randn(2, 128, 24, device="cuda")).requires_grad_(True)
+    qf = 0.5 * torch.randn(5, 128, 24, device="cuda")
+    xg_ref = codec.decode_embeddings(qg)
+    with torch.no_grad():
+        xf_ref = codec.decode_embeddings(qf)
+    gy = torch.randn_like(xg_ref)
+    g_ref, = torch.autograd.grad(xg_ref, qg, gy)
+    xg, xf = codec.decode_embeddings_mixed(qg, qf)
+    g_mix, = torch.autograd.grad(xg, qg, gy)
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    for got, want, name in ((xg, xg_ref, "x_grad"), (xf, xf_ref, "x_frozen"), (g_mix, g_ref, "dq")):
+        scale = float(want.abs().max())
+        assert float((got.float() - want.float()).abs().max()) <= tol * scale, name
