@@ -27,7 +27,7 @@ sys.path.insert(0, str(REPO))
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_NAMES = {0: "conv_direct_kernel", 1: "conv_fewout_kernel", 2: "conv_cin1_kernel",
                 3: "conv_mfma_kernel<1,4,32>", 4: "conv_mfma_kernel<2,2,64>", 5: "conv_fewout_rows_kernel",
-                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<1,4>", 8: "conv_gemm_kernel<2,2>"}
+                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>"}
 
 
 def make_models(precision: str, device, seed: int):
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,12 +150,20 @@ def main():
         step(args.warmup + args.steps)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-        for kid, flops, e0, e1 in prof:
+        if args.conv_table:
+            rows = {}
+            for kid, flops, e0, e1, shape in prof:
+                r = rows.setdefault((kid,) + shape, [0, 0.0, 0.0])
+                r[0] += 1; r[1] += flops; r[2] += e0.elapsed_time(e1)
+            print("kernel  (B, Cin, M, J, Lout, nphase, in_stride, pre_act)  launches  ms  TFLOP/s", file=sys.stderr)
+            for key, r in sorted(rows.items(), key=lambda kv: -kv[1][2]):
+                print(f"{KERNEL_NAMES[key[0]]:26s} {str(key[1:]):44s} {r[0]:3d} {r[2]:8.3f} {r[1] / max(r[2], 1e-9) / 1e9:8.1f}", file=sys.stderr)
+        for kid, flops, e0, e1, _shape in prof:
             k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "ms": 0.0})
             k["launches"] += 1
             k["flops"] += flops
             k["ms"] += e0.elapsed_time(e1)
-        dom = max((k for k in kernels if k in (3, 4, 7, 8)), key=lambda k: kernels[k]["ms"], default=None)
+        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9)), key=lambda k: kernels[k]["ms"], default=None)
         if dom is not None:
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12

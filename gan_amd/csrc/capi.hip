@@ -47,7 +47,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
     const bool big = (long)p.Lout * p.B >= 64 || p.out_f32;
-    if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
+    if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
     const bool mfma = ((impl == GA_IMPL_MFMA || impl == GA_IMPL_MFMA_WINDOW) && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && big);
     if (mfma) return p.M <= 64 ? GA_KERNEL_MFMA_64x128 : GA_KERNEL_MFMA_128x128;
     if (p.in_stride >= 1 && ga_thin_conv_supported(p, dtype)) return p.M <= 4 ? GA_KERNEL_THIN_FEWOUT_ROWS : GA_KERNEL_THIN_CIN1_VEC;

@@ -34,13 +34,16 @@ __device__ __forceinline__ uintptr_t sel_addr(bool ok, uintptr_t a, uintptr_t z)
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
 }
 
-template <int WM, int WN, int NBUF>
+// MI: 32-row MFMA tiles per wave along m (2: wave tile 64 x 64, 1: wave tile 32 x 64 for layers with <= 32 output channels)
+template <int MI, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot) {
-    constexpr int BM = WM * 64, BN = WN * 64;
-    constexpr int NA = BM * 8 / 256;  // 16-byte pieces per thread per K-step, A (weights)
-    constexpr int NB = BN * 8 / 256;  // same, B (gathered activations)
+    constexpr int WMR = MI * 32;               // rows (m) per wave
+    constexpr int BM = WM * WMR, BN = WN * 64;
+    constexpr int NA = (BM * 8 + 255) / 256;   // 16-byte pieces per thread per K-step, A (weights)
+    constexpr int NB = BN * 8 / 256;           // same, B (gathered activations)
+    constexpr int EPF = WMR + 4;               // floats per staged epilogue row (odd number of 16-byte slots)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    // [2][BM*128] A, then [2][BN*128] B
+    // [NBUF][BM*128] A, then [NBUF][BN*128] B; reused by the epilogue as 4 x [32][EPF] floats
     char* const Al = smem;
     char* const Bl = smem + NBUF * BM * 128;
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = mbase + i * 32 + srow;
-        arow[i] = m < p.M ? w + (size_t)m * Ktot : nullptr;
+        arow[i] = (m < p.M && i * 32 + srow < BM) ? w + (size_t)m * Ktot : nullptr;
     }
     const bf16_t* brow[NB];
     int bR[NB];
@@ -107,16 +110,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
     const int swz = (r >> 1) & 7;
-    const int aoff = (wm * 64 + r) * 128, boff = (wn * 64 + r) * 128;
+    const int aoff = (wm * WMR + r) * 128, boff = (wn * 64 + r) * 128;
 
     if (NBUF == 2) issue(0, 0);
     for (int ks = 0; ks < nsteps; ++ks) {
@@ -133,78 +136,92 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int po = ((kk * 2 + h) ^ swz) << 4;
-            bf16x8 a[2], b[2];
+            bf16x8 a[MI], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8*)(Ab + mi * 32 * 128 + po);
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(Ab + mi * 32 * 128 + po);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) b[ni] = *(const bf16x8*)(Bb + ni * 32 * 128 + po);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
 
-    if (mbase + wm * 64 >= p.M) return;
+    // ---- epilogue: accumulators -> wave-private LDS rows [n][m] -> 16-byte, row-contiguous global accesses ----
+    __syncthreads();  // every wave is done with the operand tiles; their LDS is reused below
+    if (mbase + wm * WMR >= p.M) return;
+    float* const stage = (float*)smem + wid * (32 * EPF);
     bf16_t* __restrict__ y = (bf16_t*)p.y;
     const bf16_t* __restrict__ res = (const bf16_t*)p.res;
     const bf16_t* __restrict__ ds = (const bf16_t*)p.dact_src;
+    constexpr int LPR = WMR / 8;        // lanes per staged row (8 output channels each)
+    constexpr int RPP = 64 / LPR;       // rows per pass
+    const int erow = lane / LPR, ec8 = (lane % LPR) * 8;
+    const int m0 = mbase + wm * WMR + ec8;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int n = nbase + wn * 64 + ni * 32 + r;
-        if (n >= Ntot) continue;
-        const int b = n / p.Lout, t = p.t0 + (n - b * p.Lout);
-        const int orow = t * p.out_stride + phase;
-        if (orow < 0 || orow >= p.LoutTot) continue;
-        const size_t rowbase = ((size_t)b * p.LoutTot + orow) * p.M;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m0 = mbase + wm * 64 + mi * 32 + 8 * q + 4 * h;
-                if (m0 >= p.M) continue;
-                float v[4];
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(stage + r * EPF + mi * 32 + 8 * q + 4 * h) =
+                    make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][4 * q + i];
-                if (p.bias) {
-                    const float4 bv = *(const float4*)(p.bias + m0);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + erow;
+            const int n = nbase + wn * 64 + ni * 32 + row;
+            if (n >= Ntot || m0 >= p.M) continue;
+            const int b = n / p.Lout, t = p.t0 + (n - b * p.Lout);
+            const int orow = t * p.out_stride + phase;
+            if (orow < 0 || orow >= p.LoutTot) continue;
+            const size_t o = ((size_t)b * p.LoutTot + orow) * p.M + m0;
+            float v[8];
+            *(float4*)&v[0] = *(const float4*)(stage + row * EPF + ec8);
+            *(float4*)&v[4] = *(const float4*)(stage + row * EPF + ec8 + 4);
+            if (p.bias) {
+                const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = act_apply(p.post_act, v[i]);
-                if (p.dact_mode) {
-                    const bf16x4 d = *(const bf16x4*)(ds + rowbase + m0);
+            for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i]);
+            if (p.dact_mode) {
+                const bf16x8 d = *(const bf16x8*)(ds + o);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
-                }
-                if (res) {
-                    const bf16x4 d = *(const bf16x4*)(res + rowbase + m0);
+                for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
+            }
+            if (res) {
+                const bf16x8 d = *(const bf16x8*)(res + o);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)d[i];
-                }
-                if (p.accumulate) {
-                    const bf16x4 d = *(const bf16x4*)(y + rowbase + m0);
+                for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+            }
+            if (p.accumulate) {
+                const bf16x8 d = *(const bf16x8*)(y + o);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)d[i];
-                }
-                if (p.out_f32) {
-                    *(float4*)((float*)p.y + rowbase + m0) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16x4 o;
+                for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+            }
+            if (p.out_f32) {
+                float* yo = (float*)p.y + o;
+                *(float4*)yo = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                bf16x8 ov;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-                    *(bf16x4*)(y + rowbase + m0) = o;
-                }
+                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                *(bf16x8*)(y + o) = ov;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 int ga_conv_gemm_supported(const ConvParams& p) {
     if (p.pre_act != GA_ACT_NONE) return 0;  // direct-to-LDS loads cannot transform the operand in flight
-    if (p.Cin % 8 || p.Cin < 8 || p.M % 4 || p.M < 33 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if (p.Cin % 8 || p.Cin < 8 || p.M % 8 || p.M < 16 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
     if (p.nphase < 1 || p.nphase > GA_MAX_PHASE) return 0;
     if (p.out_f32 && (p.res || p.dact_src || p.accumulate)) return 0;
     if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
@@ -222,9 +239,9 @@ static int gemm_nbuf_override() {
     return v;
 }
 
-template <int WM, int WN, int NBUF>
+template <int MI, int WM, int WN, int NBUF>
 static int launch_gemm(const ConvParams& p, hipStream_t s) {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * 64;
     const int Ntot = p.B * p.Lout;
     const int nN = (Ntot + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
     const long total = (long)nN * nM * p.nphase;
@@ -232,8 +249,10 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     if (total > (1L << 30)) return GA_ERR_ARG;
     const int Ktot = p.J * p.Cin;
     const int nsteps = (Ktot + GBK - 1) / GBK;
-    const size_t lds = NBUF * (BM + BN) * 128;
-    auto kern = conv_gemm_kernel<WM, WN, NBUF>;
+    size_t lds = NBUF * (BM + BN) * 128;
+    const size_t epi = 4 * 32 * (MI * 32 + 4) * sizeof(float);
+    if (lds < epi) lds = epi;
+    auto kern = conv_gemm_kernel<MI, WM, WN, NBUF>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return GA_ERR_LAUNCH;
@@ -247,11 +266,16 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
-    if (p.M <= 64) return launch_gemm<1, 4, 2>(p, s);
+    // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
+    // wants the second buffer
+    const int ksteps = (p.J * p.Cin + GBK - 1) / GBK;
+    const int nb_small = gemm_nbuf_override() ? gemm_nbuf_override() : (ksteps <= 8 ? 1 : 2);
+    if (p.M <= 32) return nb_small == 1 ? launch_gemm<1, 1, 4, 1>(p, s) : launch_gemm<1, 1, 4, 2>(p, s);
+    if (p.M <= 64) return nb_small == 1 ? launch_gemm<2, 1, 4, 1>(p, s) : launch_gemm<2, 1, 4, 2>(p, s);
     // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
     // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
     const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase;
     int nbuf = gemm_nbuf_override();
     if (!nbuf) nbuf = blocks >= 600 ? 1 : 2;
-    return nbuf == 1 ? launch_gemm<2, 2, 1>(p, s) : launch_gemm<2, 2, 2>(p, s);
+    return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
 }

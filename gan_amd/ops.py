@@ -141,7 +141,8 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
     e0.record()
     L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
     e1.record()
-    PROFILE.append((kid, 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin, e0, e1))
+    PROFILE.append((kid, 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin, e0, e1,
+                    (p.B, p.Cin, p.M, p.J, p.Lout, p.nphase, p.in_stride, p.pre_act)))
 
 
 _IMPL = L.IMPL_AUTO
@@ -181,7 +182,7 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
                   tap_step=g.dilation, off0=0, t0=1, accumulate=1, dact_mode=dact_mode)
             # the gathered-GEMM kernel takes any row stride (bf16); otherwise the direct kernel
             kid = L.lib().ga_conv_kernel_id(C.byref(q), L.dt(gy), L.IMPL_MFMA) if _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) else -1
-            fix_impl = L.IMPL_MFMA if kid in (L.KERNEL_GEMM_64x256, L.KERNEL_GEMM_128x128) else L.IMPL_DIRECT
+            fix_impl = L.IMPL_MFMA if kid in L.GEMM_KERNELS else L.IMPL_DIRECT
             _launch_conv(q, gy, wp_d, dx, dact_src=dact_src, impl=fix_impl)
     return dx
 

@@ -92,8 +92,9 @@ int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t str
 #define GA_KERNEL_MFMA_128x128 4 /* conv_mfma_kernel<2,2,64> */
 #define GA_KERNEL_THIN_FEWOUT_ROWS 5
 #define GA_KERNEL_THIN_CIN1_VEC 6
-#define GA_KERNEL_GEMM_64x256 7  /* conv_gemm_kernel<1,4> */
-#define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2> */
+#define GA_KERNEL_GEMM_64x256 7  /* conv_gemm_kernel<2,1,4> */
+#define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2,2> */
+#define GA_KERNEL_GEMM_32x256 9  /* conv_gemm_kernel<1,1,4> */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]

@@ -135,6 +135,9 @@ GEMM_CASES = [
     (ConvGeom("convt", 512, 256, 16, 8), 40, 2),
     (ConvGeom("cconv", 128, 512, 7), 375, 2),              # causal reflect conv (dgrad needs the mirrored fix-up launch)
     (ConvGeom("cconv", 64, 128, 1), 500, 2),
+    (ConvGeom("convt", 64, 32, 4, 2), 400, 3),             # decoder tail: 32 and 16 output channels (32 x 256 tile)
+    (ConvGeom("cconv", 32, 16, 3), 901, 2),
+    (ConvGeom("cconv", 16, 32, 1), 901, 2),
 ]
 
 
@@ -151,7 +154,7 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
     p = ops.fwd_params(g, B, Ln)
     kid = L.lib().ga_conv_kernel_id(__import__("ctypes").byref(p), 1, L.IMPL_AUTO)
-    assert kid in (L.KERNEL_GEMM_64x256, L.KERNEL_GEMM_128x128), kid
+    assert kid in L.GEMM_KERNELS, kid
     outs = {}
     for impl in (L.IMPL_MFMA, L.IMPL_DIRECT):
         ops.set_conv_impl(impl)
