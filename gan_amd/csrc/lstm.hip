@@ -226,9 +226,36 @@ __device__ __forceinline__ void seg_mma(const WT* a_row, const WT* const (&b_row
     }
 }
 
-template <typename WT, typename AT, int H, int NBT>
-__global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, int s, int b_base) {
-    __shared__ float red[4][NBT][16][17];
+// two K segments in ONE burst (backward, layer 1): all loads of both, then all MFMAs
+template <typename WT, int NK, int NBT>
+__device__ __forceinline__ void seg_mma2(const WT* a0, const WT* const (&b0)[NBT], const WT* a1, const WT* const (&b1)[NBT], int kq,
+                                         f32x4 (&acc)[NBT]) {
+    typedef typename Mma<WT>::V V;
+    constexpr int KS = Mma<WT>::KSTEP;
+    V a[2][NK], b[2][NBT][NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        a[0][s] = Mma<WT>::load(a0, s * KS, kq);
+        a[1][s] = Mma<WT>::load(a1, s * KS, kq);
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+            b[0][i][s] = Mma<WT>::load(b0[i], s * KS, kq);
+            b[1][i][s] = Mma<WT>::load(b1[i], s * KS, kq);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NK; ++s)
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+            acc[i] = Mma<WT>::mma(a[0][s], b[0][i][s], acc[i]);
+            acc[i] = Mma<WT>::mma(a[1][s], b[1][i][s], acc[i]);
+        }
+}
+
+template <typename WT, typename AT, int H, int NBT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_fast_kernel(ga_lstm_params p, int s, int b_base) {
+    __shared__ float red[NW][NBT][16][17];
     constexpr int KS = Mma<WT>::KSTEP;
     const int layer = blockIdx.y;
     const int t = layer == 0 ? s : s - 1;
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, in
     WT* hout = layer == 0 ? (WT*)p.h1 : (WT*)p.h2;
 
     // epilogue role (tile, unit, batch column) and its inputs, requested first
-    const int e_tile = tid >> 6, e_uu = (tid >> 4) & 3, e_bb = tid & 15;
+    const int e_tile = tid >> 6, e_uu = tid & 3, e_bb = (tid >> 2) & 15;  // unit fastest: 4 lanes share a row segment
     const int e_b = b_base + e_tile * 16 + e_bb, e_u = u0 + e_uu;
     const bool e_on = e_tile < NBT && e_b < p.B;
     // (unconditional raw loads from clamped addresses: a branch, a conversion or a per-element select here would make
@@ -269,17 +296,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, in
     }
     if (layer == 0) {
         if (t > 0) {
-            constexpr int NK = H / KS / 4;
-            const WT* a = (const WT*)p.w1 + (size_t)arow * H + wid * (H / 4);
+            constexpr int NK = H / KS / NW;
+            const WT* a = (const WT*)p.w1 + (size_t)arow * H + wid * (H / NW);
             const WT* b[NBT];
 #pragma unroll
-            for (int i = 0; i < NBT; ++i) b[i] = h1 + ((size_t)bld[i] * p.T + (t - 1)) * H + wid * (H / 4);
+            for (int i = 0; i < NBT; ++i) b[i] = h1 + ((size_t)bld[i] * p.T + (t - 1)) * H + wid * (H / NW);
             seg_mma<WT, NK, NBT>(a, b, kq, acc);
         }
     } else {
-        // combined K = [h1_t | h2_{t-1}]: waves 0,1 take the h1 half, waves 2,3 the h2 half (absent at t = 0)
-        constexpr int NK = 2 * H / KS / 4;
-        const int koff = wid * (H / 2);
+        // combined K = [h1_t | h2_{t-1}]: the first half of the waves takes the h1 half, the rest the h2 half (absent at t = 0)
+        constexpr int NK = 2 * H / KS / NW;
+        const int koff = wid * (2 * H / NW);
         if (koff < H || t > 0) {
             const WT* a = (const WT*)p.w2 + (size_t)arow * 2 * H + koff;
             const WT* b[NBT];
@@ -304,7 +331,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, in
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int r = g * 4 + e_uu;
-            pre[g] += red[0][e_tile][r][e_bb] + red[1][e_tile][r][e_bb] + red[2][e_tile][r][e_bb] + red[3][e_tile][r][e_bb];
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) pre[g] += red[w8][e_tile][r][e_bb];
         }
         const float ig = sigm(pre[0]), fg = sigm(pre[1]), gg = tanhf(pre[2]), og = sigm(pre[3]);
         const float c = fg * c_prev + ig * gg;
@@ -321,11 +349,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fast_kernel(ga_lstm_params p, in
     }
 }
 
-template <typename WT, typename AT, int H, int NBT>
-__global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p, int s, int b_base) {
-    __shared__ float red[4][NBT][16][17];
+template <typename WT, typename AT, int H, int NBT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p, int s, int b_base) {
+    __shared__ float red[NW][NBT][16][17];
     constexpr int KS = Mma<WT>::KSTEP;
-    constexpr int NK = 4 * H / KS / 4;
+    constexpr int NK = 4 * H / KS / NW;
     const int layer = blockIdx.y;  // 0: layer 2 (leads), 1: layer 1
     const int t = layer == 0 ? p.T - 1 - s : p.T - s;
     if (t < 0 || t >= p.T) return;
@@ -339,8 +367,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p
     float* dcs = layer == 0 ? p.dc2 : p.dc1;
     WT* dgout = layer == 0 ? (WT*)p.dg2 : (WT*)p.dg1;
 
-    // epilogue role: 256 threads = 16 units x 16 batch columns, looped over the NBT tiles; inputs requested first
-    const int e_uu = tid >> 4, e_bb = tid & 15, e_u = u0 + e_uu;
+    // epilogue role: threads 0..255 = 16 units x 16 batch columns, looped over the NBT tiles; inputs requested first
+    // (unit fastest: one load instruction covers 16 consecutive units = 64 contiguous bytes of 4 batch rows)
+    const int e_uu = tid & 15, e_bb = (tid >> 4) & 15, e_u = u0 + e_uu;
+    const bool e_on = tid < 256;
     float e_ig[NBT], e_fg[NBT], e_gg[NBT], e_og[NBT], e_c[NBT], e_cp[NBT], e_dc[NBT];
     AT e_dyr[NBT];
 #pragma unroll
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p
         const int bcol = b_base + i * 16 + rc;
         bld[i] = bcol < p.B ? bcol : p.B - 1;
     }
-    const int koff = wid * H;  // this wave's quarter of K = 4H
+    const int koff = wid * (4 * H / NW);  // this wave's share of K = 4H
     const WT* b[NBT];
     if (layer == 0) {
         // dh2_t[u] = dy_t[u] + sum_k dg2_{t+1}[k] * W_hh_l1[k][u]       (w2t row H + u)
@@ -378,11 +408,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p
         // dh1_t[u] = sum_k dg2_t[k] * W_ih_l1[k][u] + sum_k dg1_{t+1}[k] * W_hh_l0[k][u]
 #pragma unroll
         for (int i = 0; i < NBT; ++i) b[i] = dg2 + ((size_t)bld[i] * p.T + t) * 4 * H + koff;
-        seg_mma<WT, NK, NBT>((const WT*)p.w2t + (size_t)(u0 + rc) * 4 * H + koff, b, kq, acc);
+        const WT* a2 = (const WT*)p.w2t + (size_t)(u0 + rc) * 4 * H + koff;
         if (t + 1 < p.T) {
+            const WT* bn[NBT];
 #pragma unroll
-            for (int i = 0; i < NBT; ++i) b[i] = dg1 + ((size_t)bld[i] * p.T + (t + 1)) * 4 * H + koff;
-            seg_mma<WT, NK, NBT>((const WT*)p.w1t + (size_t)(u0 + rc) * 4 * H + koff, b, kq, acc);
+            for (int i = 0; i < NBT; ++i) bn[i] = dg1 + ((size_t)bld[i] * p.T + (t + 1)) * 4 * H + koff;
+            const WT* a1 = (const WT*)p.w1t + (size_t)(u0 + rc) * 4 * H + koff;
+            if constexpr (sizeof(WT) == 2 && NK * (1 + NBT) <= 16) {
+                seg_mma2<WT, NK, NBT>(a2, b, a1, bn, kq, acc);
+            } else {
+                seg_mma<WT, NK, NBT>(a2, b, kq, acc);
+                seg_mma<WT, NK, NBT>(a1, bn, kq, acc);
+            }
+        } else {
+            seg_mma<WT, NK, NBT>(a2, b, kq, acc);
         }
     }
 #pragma unroll
@@ -393,8 +432,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p
 #pragma unroll
     for (int i = 0; i < NBT; ++i) {
         const int bq = b_base + i * 16 + e_bb;
-        if (bq < p.B) {
-            const float dh = red[0][i][e_uu][e_bb] + red[1][i][e_uu][e_bb] + red[2][i][e_uu][e_bb] + red[3][i][e_uu][e_bb] + (layer == 0 ? (float)e_dyr[i] : 0.f);
+        if (bq < p.B && e_on) {
+            float dh = layer == 0 ? (float)e_dyr[i] : 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) dh += red[w8][i][e_uu][e_bb];
             const float cprev = t > 0 ? e_cp[i] : 0.f;
             const float ig = e_ig[i], fg = e_fg[i], gg = e_gg[i], og = e_og[i];
             const float tc = tanhf(e_c[i]);
@@ -409,27 +450,35 @@ __global__ __launch_bounds__(256) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p
     }
 }
 
+#ifndef GA_LSTM_FNW
+#define GA_LSTM_FNW 4
+#endif
+#ifndef GA_LSTM_BNW
+#define GA_LSTM_BNW 8
+#endif
 template <typename WT, typename AT, int H>
 static void launch_fwd_fast(const ga_lstm_params& p, int st, hipStream_t s) {
+    constexpr int FNW = GA_LSTM_FNW;
     const dim3 grid(H / 4, 2);
     for (int b0 = 0; b0 < p.B; b0 += 64) {
         const int nbt = (((p.B - b0) < 64 ? (p.B - b0) : 64) + 15) / 16;
         switch (nbt) {
-            case 1: lstm_fwd_fast_kernel<WT, AT, H, 1><<<grid, 256, 0, s>>>(p, st, b0); break;
-            case 2: lstm_fwd_fast_kernel<WT, AT, H, 2><<<grid, 256, 0, s>>>(p, st, b0); break;
-            case 3: lstm_fwd_fast_kernel<WT, AT, H, 3><<<grid, 256, 0, s>>>(p, st, b0); break;
-            default: lstm_fwd_fast_kernel<WT, AT, H, 4><<<grid, 256, 0, s>>>(p, st, b0); break;
+            case 1: lstm_fwd_fast_kernel<WT, AT, H, 1, FNW><<<grid, FNW * 64, 0, s>>>(p, st, b0); break;
+            case 2: lstm_fwd_fast_kernel<WT, AT, H, 2, FNW><<<grid, FNW * 64, 0, s>>>(p, st, b0); break;
+            case 3: lstm_fwd_fast_kernel<WT, AT, H, 3, FNW><<<grid, FNW * 64, 0, s>>>(p, st, b0); break;
+            default: lstm_fwd_fast_kernel<WT, AT, H, 4, FNW><<<grid, FNW * 64, 0, s>>>(p, st, b0); break;
         }
     }
 }
 
 template <typename WT, typename AT, int H>
 static void launch_bwd_fast(const ga_lstm_bwd_params& p, int st, hipStream_t s) {
+    constexpr int BNW = GA_LSTM_BNW;
     const dim3 grid(H / 16, 2);
     for (int b0 = 0; b0 < p.B; b0 += 32) {
         const int nbt = (((p.B - b0) < 32 ? (p.B - b0) : 32) + 15) / 16;
-        if (nbt == 1) lstm_bwd_fast_kernel<WT, AT, H, 1><<<grid, 256, 0, s>>>(p, st, b0);
-        else lstm_bwd_fast_kernel<WT, AT, H, 2><<<grid, 256, 0, s>>>(p, st, b0);
+        if (nbt == 1) lstm_bwd_fast_kernel<WT, AT, H, 1, BNW><<<grid, BNW * 64, 0, s>>>(p, st, b0);
+        else lstm_bwd_fast_kernel<WT, AT, H, 2, BNW><<<grid, BNW * 64, 0, s>>>(p, st, b0);
     }
 }
 
