@@ -142,6 +142,161 @@ __global__ __launch_bounds__(256) void conv_cin1_vec_kernel(ConvParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variants.  The per-thread kernels above re-read every input row once per tap through L1 (and re-apply
+// the ELU prologue each time); here a block stages its input window ONCE with coalesced 16-byte loads (prologue
+// activation applied once), and all tap reads come from LDS.
+//
+// M <= 4: block = 256 consecutive output steps of one (batch item, phase); LDS rows are padded to an odd number of
+// 16-byte slots so that the lanes' ds_read_b128 of consecutive rows do not collide.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_fewout_lds_kernel(ConvParams p, int span, int pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wsm = (float*)smem_raw;                                  // [M][J*Cin]
+    const int KC = p.J * p.Cin;
+    char* xs = smem_raw + (((size_t)p.M * KC * 4 + 15) & ~(size_t)15);  // [span][pitch]
+    const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+    const T* __restrict__ w = (const T*)p.w + (size_t)phase * p.M * KC;
+    const T* __restrict__ x = (const T*)p.x + (size_t)b * p.Lin * p.Cin;
+    for (int i = threadIdx.x; i < p.M * KC; i += 256) wsm[i] = (float)w[i];
+    const int off0 = p.off0 + p.phase_off0[phase];
+    const int tblk = p.t0 + blockIdx.x * 256;
+    const int R0 = tblk * p.in_stride + off0;
+    const int parts = p.Cin / 8;
+    for (int idx = threadIdx.x; idx < span * parts; idx += 256) {
+        const int row = idx / parts, part = idx - row * parts;
+        int R = R0 + row;
+        if (R < 0 && p.pad_mode == 1) R = -R;
+        Vec8<T> v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
+        if (R >= 0 && R < p.Lin) {
+            v.load(x + (size_t)R * p.Cin + part * 8);
+            if (p.pre_act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = act_apply(p.pre_act, v.v[e]);
+            }
+        }
+        v.store((T*)(xs + (size_t)row * pitch) + part * 8);
+    }
+    __syncthreads();
+    const int t = tblk + threadIdx.x;
+    if (t >= p.t0 + p.Lout) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < p.J; ++j) {
+        const T* xr = (const T*)(xs + (size_t)(threadIdx.x * p.in_stride + j * p.tap_step) * pitch);
+        const float* wj = wsm + j * p.Cin;
+        for (int c = 0; c < p.Cin; c += 8) {
+            Vec8<T> xv;
+            xv.load(xr + c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < p.M) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[m] = fmaf(xv.v[e], wj[m * KC + c + e], acc[m]);
+                }
+            }
+        }
+    }
+    const int orow = t * p.out_stride + phase;
+    if (orow < 0 || orow >= p.LoutTot) return;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m >= p.M) continue;
+        const size_t idx = ((size_t)b * p.LoutTot + orow) * p.M + m;
+        float v = acc[m];
+        if (p.bias) v += p.bias[m];
+        v = act_apply(p.post_act, v);
+        if (p.dact_mode) v *= dact_apply(p.dact_mode, (float)((const T*)p.dact_src)[idx]);
+        if (p.res) v += (float)((const T*)p.res)[idx];
+        if (p.out_f32) { ((float*)p.y)[idx] = v; continue; }
+        if (p.accumulate) v += (float)((T*)p.y)[idx];
+        ((T*)p.y)[idx] = (T)v;
+    }
+}
+
+// Cin == 1, M % 8 == 0, J <= 16 (D block 0): a block covers CIN1_ROWS output steps; the input window sits in LDS as
+// floats, every thread keeps the J x 8 weights of its 8 output channels in registers and writes 16-byte pieces, so one
+// wave instruction stores whole contiguous output rows.
+#define CIN1_ROWS 2048
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin1_lds_kernel(ConvParams p, int span) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ws = (float*)smem_raw;          // [J][M], transposed so a thread's 8 channels are contiguous
+    float* xs = ws + ((p.J * p.M + 3) & ~3);  // [span]
+    const int b = blockIdx.z;
+    const T* __restrict__ x = (const T*)p.x + (size_t)b * p.Lin;
+    const T* __restrict__ w = (const T*)p.w;
+    for (int i = threadIdx.x; i < p.M * p.J; i += 256) ws[(i % p.J) * p.M + i / p.J] = (float)w[i];
+    const int tblk = p.t0 + blockIdx.x * CIN1_ROWS;
+    const int R0 = tblk * p.in_stride + p.off0;
+    for (int i = threadIdx.x; i < span; i += 256) {
+        int R = R0 + i;
+        if (R < 0 && p.pad_mode == 1) R = -R;
+        float v = (R >= 0 && R < p.Lin) ? (float)x[R] : 0.f;
+        if (p.pre_act) v = act_apply(p.pre_act, v);
+        xs[i] = v;
+    }
+    const int parts = p.M / 8, rows_per_pass = 256 / parts;
+    const int part = threadIdx.x % parts, rl = threadIdx.x / parts;
+    const int m0 = part * 8;
+    float wr[16][8], bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[i] = p.bias ? p.bias[m0 + i] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int jc = j < p.J ? j : 0;
+        const float4 w0 = *(const float4*)(ws + jc * p.M + m0), w1 = *(const float4*)(ws + jc * p.M + m0 + 4);
+        const float keep = j < p.J ? 1.f : 0.f;
+        wr[j][0] = w0.x * keep; wr[j][1] = w0.y * keep; wr[j][2] = w0.z * keep; wr[j][3] = w0.w * keep;
+        wr[j][4] = w1.x * keep; wr[j][5] = w1.y * keep; wr[j][6] = w1.z * keep; wr[j][7] = w1.w * keep;
+    }
+    if (rl >= rows_per_pass) return;
+    int tend = p.t0 + p.Lout - tblk;
+    if (tend > CIN1_ROWS) tend = CIN1_ROWS;
+    for (int tl = rl; tl < tend; tl += rows_per_pass) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = bs[i];
+        const float* xw = xs + tl * p.in_stride;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < p.J) {
+                const float xv = xw[j * p.tap_step];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wr[j][i], acc[i]);
+            }
+        }
+        const int orow = (tblk + tl) * p.out_stride;
+        if (orow >= p.LoutTot) continue;
+        const size_t idx = ((size_t)b * p.LoutTot + orow) * p.M + m0;
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = act_apply(p.post_act, acc[i]);
+        if (p.dact_mode) {
+            Vec8<T> d;
+            d.load((const T*)p.dact_src + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] *= dact_apply(p.dact_mode, d.v[i]);
+        }
+        if (p.res) {
+            Vec8<T> d;
+            d.load((const T*)p.res + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] += d.v[i];
+        }
+        if (p.accumulate) {
+            Vec8<T> d;
+            d.load((T*)p.y + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] += d.v[i];
+        }
+        o.store((T*)p.y + idx);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient, Cin == 1, M % 8 == 0, J <= 16:  dw[m][j] += sum_{b,t} g[b][t][m] * x[b][t*S + j*step + off0]
 // and, fused, the bias gradient db[m] += sum g.  A block owns a run of consecutive steps of one batch item.
@@ -175,20 +330,31 @@ __global__ __launch_bounds__(256) void wgrad_cin1_kernel(WgradParams p, float* _
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     }
     if (rl < lanes) {
-        for (int r = rl; r < nrows; r += lanes) {
-            Vec8<T> gv;
-            gv.load(g + ((size_t)b * p.LgTot + (size_t)(t0 + r) * p.g_stride + p.g_phase) * p.M + part * 8);
-            const float* xw = xs + r * p.in_stride;
+        // 2 rows per trip, their loads issued together (the kernel is HBM-latency-bound otherwise)
+        for (int r0 = rl; r0 < nrows; r0 += 2 * lanes) {
+            Vec8<T> gv[2];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j < p.J) {
-                    const float xv = xw[j * p.tap_step];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i][j] = fmaf(gv.v[i], xv, acc[i][j]);
-                }
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u * lanes;
+                const int rc = r < nrows ? r : nrows - 1;
+                gv[u].load(g + ((size_t)b * p.LgTot + (size_t)(t0 + rc) * p.g_stride + p.g_phase) * p.M + part * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) accb[i] += gv.v[i];
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u * lanes;
+                if (r >= nrows) continue;
+                const float* xw = xs + r * p.in_stride;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j < p.J) {
+                        const float xv = xw[j * p.tap_step];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i][j] = fmaf(gv[u].v[i], xv, acc[i][j]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) accb[i] += gv[u].v[i];
+            }
         }
     }
     // reduce over the row lanes: 17 values (16 taps + bias) per (part, channel)
@@ -309,14 +475,31 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <typename T>
 static int thin_conv_t(const ConvParams& p, hipStream_t s) {
     if (p.M <= 4) {
-        int gx = (p.Lout + 255) / 256;
-        if (gx > 16384) gx = 16384;
-        conv_fewout_rows_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, (size_t)p.M * p.J * p.Cin * sizeof(float), s>>>(p);
+        // LDS-staged window when it fits (64 KiB) and the block grid stays within limits
+        const long span = 255L * p.in_stride + (long)(p.J - 1) * p.tap_step + 1;
+        const int pitch = p.Cin * (int)sizeof(T) + 16;
+        const size_t wbytes = ((size_t)p.M * p.J * p.Cin * 4 + 15) & ~(size_t)15;
+        const size_t lds = wbytes + (size_t)span * pitch;
+        const long gxl = ((long)p.Lout + 255) / 256;
+        if (p.in_stride >= 1 && p.tap_step >= 0 && lds <= 64 * 1024 && gxl <= 0x7fffffffL && (long)p.B * p.nphase <= 65535) {
+            conv_fewout_lds_kernel<T><<<dim3((unsigned)gxl, 1, p.B * p.nphase), 256, lds, s>>>(p, (int)span, pitch);
+        } else {
+            int gx = (p.Lout + 255) / 256;
+            if (gx > 16384) gx = 16384;
+            conv_fewout_rows_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, (size_t)p.M * p.J * p.Cin * sizeof(float), s>>>(p);
+        }
     } else {
-        const size_t total = (size_t)p.Lout * (p.M / 8);
-        size_t gx = (total + 255) / 256;
-        if (gx > 8192) gx = 8192;
-        conv_cin1_vec_kernel<T><<<dim3((unsigned)gx, 1, p.B), 256, (size_t)(p.M * p.J + p.M) * sizeof(float), s>>>(p);
+        const long span = (long)(CIN1_ROWS - 1) * p.in_stride + (long)(p.J - 1) * p.tap_step + 1;
+        const size_t lds1 = (size_t)(((p.J * p.M + 3) & ~3) + span) * 4;
+        if (p.J <= 16 && p.M <= 256 && 256 % (p.M / 8) == 0 && p.in_stride >= 1 && p.tap_step >= 0 && lds1 <= 60 * 1024 && p.B <= 65535) {
+            const unsigned gx = (unsigned)((p.Lout + CIN1_ROWS - 1) / CIN1_ROWS);
+            conv_cin1_lds_kernel<T><<<dim3(gx, 1, p.B), 256, lds1, s>>>(p, (int)span);
+        } else {
+            const size_t total = (size_t)p.Lout * (p.M / 8);
+            size_t gx = (total + 255) / 256;
+            if (gx > 8192) gx = 8192;
+            conv_cin1_vec_kernel<T><<<dim3((unsigned)gx, 1, p.B), 256, (size_t)(p.M * p.J + p.M) * sizeof(float), s>>>(p);
+        }
     }
     GA_CHECK_LAUNCH();
     return GA_OK;

@@ -53,6 +53,10 @@ TRAIN_CASES = [
     (ConvGeom("conv", 128, 256, 41, 4, 20, 1), 375, True, L.ACT_LRELU),     # D block 3
     (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 259, True, L.ACT_LRELU),     # D block 4
     (ConvGeom("conv", 512, 1, 3, 1, 1, 1), 65, True, L.ACT_NONE),           # D logits conv (Cout = 1)
+    # long enough for the HBM-bound thin kernels (LDS-staged window) to be the ones that run
+    (ConvGeom("conv", 1, 32, 15, 1, 7, 1), 6001, True, L.ACT_LRELU),
+    (ConvGeom("conv", 64, 1, 3, 1, 1, 1), 5003, True, L.ACT_NONE),
+    (ConvGeom("conv", 512, 1, 3, 1, 1, 1), 4100, True, L.ACT_NONE),
 ]
 
 
@@ -195,14 +199,14 @@ def test_mfma_weight_gradient_matches_direct():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("kind", ["cconv7", "cconv3", "cconv1", "convt8", "convt5", "convt2", "tail"])
+@pytest.mark.parametrize("kind", ["cconv7", "cconv3", "cconv1", "convt8", "convt5", "convt2", "tail", "tail_long"])
 def test_frozen_decoder_layers(kind, dtype):
     torch.manual_seed(4)
     B = 2
     geom, Ln = {"cconv7": (ConvGeom("cconv", 128, 512, 7), 40), "cconv3": (ConvGeom("cconv", 256, 128, 3), 333),
                 "cconv1": (ConvGeom("cconv", 64, 128, 1), 500), "convt8": (ConvGeom("convt", 512, 256, 16, 8), 40),
                 "convt5": (ConvGeom("convt", 256, 128, 10, 5), 70), "convt2": (ConvGeom("convt", 64, 32, 4, 2), 400),
-                "tail": (ConvGeom("cconv", 32, 1, 7), 900)}[kind]
+                "tail": (ConvGeom("cconv", 32, 1, 7), 900), "tail_long": (ConvGeom("cconv", 32, 1, 7), 7001)}[kind]
     d0, d1, k = geom.wdims
     v = torch.randn(d0, d1, k)
     gp = torch.rand(d0, 1, 1) + 0.5
