@@ -33,7 +33,7 @@ class ConvParams(C.Structure):
         ("out_stride", C.c_int), ("t0", C.c_int),
         ("pad_mode", C.c_int), ("pre_act", C.c_int), ("post_act", C.c_int), ("dact_mode", C.c_int),
         ("accumulate", C.c_int), ("nphase", C.c_int),
-        ("phase_off0", C.c_int * GA_MAX_PHASE), ("out_f32", C.c_int),
+        ("phase_off0", C.c_int * GA_MAX_PHASE), ("out_f32", C.c_int), ("ksplit", C.c_int), ("ws", C.c_void_p),
     ]
 
 
@@ -60,6 +60,8 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
     "ga_conv_kernel_id": [C.POINTER(ConvParams), _I, _I],
+    "ga_conv_suggest_ksplit": [C.POINTER(ConvParams), _I, _I],
+    "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

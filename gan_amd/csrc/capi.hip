@@ -7,6 +7,8 @@ int ga_conv_mfma_supported(const ConvParams& p);
 int ga_conv_mfma_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_supported(const ConvParams& p);
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_gemm_finish(const ConvParams& p, hipStream_t s);
+int ga_conv_gemm_suggest_ksplit(const ConvParams& p);
 int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
 int ga_wgrad_gemm_supported(const WgradParams& p);
@@ -25,6 +27,7 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
+    if (p.ksplit > 1) return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_MFMA_WINDOW) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_MFMA) return can_gemm ? ga_conv_gemm_impl(p, s) : can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_AUTO && ((long)p.Lout * p.B >= 64 || p.out_f32)) {
@@ -39,6 +42,16 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
         return p.Lout > 0 ? ga_thin_conv_impl(p, dtype, s) : GA_OK;
     }
     return ga_conv_direct_impl(p, dtype, s);
+}
+
+int ga_conv_suggest_ksplit(const ga_conv_params* hp, int dtype, int impl) {
+    if (!hp || dtype != GA_DTYPE_BF16 || (impl != GA_IMPL_AUTO && impl != GA_IMPL_MFMA)) return 1;
+    return ga_conv_gemm_suggest_ksplit(*hp);
+}
+
+int ga_conv_finish(const ga_conv_params* hp, int dtype, hipStream_t s) {
+    if (!hp || dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
+    return ga_conv_gemm_finish(*hp, s);
 }
 
 int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {

@@ -49,8 +49,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
 
     const int id = blockIdx.x;
     const int chunk = (total + 7) / 8;
-    const int wk = (id & 7) * chunk + (id >> 3);
+    int wk = (id & 7) * chunk + (id >> 3);
     if (wk >= total) return;
+    // split-K: consecutive work items are the K slices of one output tile
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int split = wk % ksplit;
+    wk /= ksplit;
+    const int ks_begin = (int)((long)nsteps * split / ksplit), ks_end = (int)((long)nsteps * (split + 1) / ksplit);
     const int my = wk / (nN * p.nphase);
     const int rem = wk - my * (nN * p.nphase);
     const int phase = rem / nN;
@@ -121,16 +126,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const int swz = (r >> 1) & 7;
     const int aoff = (wm * WMR + r) * 128, boff = (wn * 64 + r) * 128;
 
-    if (NBUF == 2) issue(0, 0);
-    for (int ks = 0; ks < nsteps; ++ks) {
-        const int buf = NBUF == 2 ? (ks & 1) : 0;
+    if (NBUF == 2 && ks_begin < ks_end) issue(ks_begin, 0);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int buf = NBUF == 2 ? ((ks - ks_begin) & 1) : 0;
         if (NBUF == 1) {
-            if (ks > 0) __syncthreads();  // everyone is done reading the single buffer
+            if (ks > ks_begin) __syncthreads();  // everyone is done reading the single buffer
             issue(ks, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // K-step ks has landed for every wave; everyone is done reading the other buffer
-        if (NBUF == 2 && ks + 1 < nsteps) issue(ks + 1, buf ^ 1);
+        if (NBUF == 2 && ks + 1 < ks_end) issue(ks + 1, buf ^ 1);
         const char* Ab = Al + buf * (BM * 128) + aoff;
         const char* Bb = Bl + buf * (BN * 128) + boff;
 #pragma unroll
@@ -181,6 +186,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
             float v[8];
             *(float4*)&v[0] = *(const float4*)(stage + row * EPF + ec8);
             *(float4*)&v[4] = *(const float4*)(stage + row * EPF + ec8 + 4);
+            if (ksplit > 1) {  // partial sums only, into this slice's own slab; ga_conv_finish adds the slabs and applies the epilogue
+                float* wo = p.ws + (size_t)split * ((size_t)p.B * p.LoutTot * p.M) + o;
+                *(float4*)wo = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(wo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                continue;
+            }
             if (p.bias) {
                 const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
                 v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -218,6 +229,85 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     }
 }
 
+// y = epi(ws) for a split-K launch: one thread per (row, 8 output channels)
+__global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, long total8) {
+    const int M8 = p.M / 8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long)gridDim.x * 256) {
+        const int m0 = (int)(e % M8) * 8;
+        long row = e / M8;
+        const int phase = (int)(row % p.nphase);
+        row /= p.nphase;
+        const int tl = (int)(row % p.Lout), b = (int)(row / p.Lout);
+        const int orow = (p.t0 + tl) * p.out_stride + phase;
+        if (orow < 0 || orow >= p.LoutTot) continue;
+        const size_t o = ((size_t)b * p.LoutTot + orow) * p.M + m0;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const size_t slab = (size_t)p.B * p.LoutTot * p.M;
+        for (int sp = 0; sp < p.ksplit; ++sp) {
+            const float4 a0 = *(const float4*)(p.ws + sp * slab + o), a1 = *(const float4*)(p.ws + sp * slab + o + 4);
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+            v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+        }
+        if (p.bias) {
+            const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i]);
+        if (p.dact_mode) {
+            const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.dact_src + o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
+        }
+        if (p.res) {
+            const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.res + o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+        }
+        if (p.out_f32) {
+            float* yo = (float*)p.y + o;
+            *(float4*)yo = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            continue;
+        }
+        if (p.accumulate) {
+            const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.y + o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+        *(bf16x8*)((bf16_t*)p.y + o) = ov;
+    }
+}
+
+int ga_conv_gemm_supported(const ConvParams& p);
+
+int ga_conv_gemm_finish(const ConvParams& p, hipStream_t s) {
+    if (!ga_conv_gemm_supported(p) || p.ksplit <= 1 || !p.ws || !p.y || ((uintptr_t)p.ws & 15)) return GA_ERR_ARG;
+    const long total8 = (long)p.B * p.Lout * p.nphase * (p.M / 8);
+    if (total8 <= 0) return GA_OK;
+    long grid = (total8 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    conv_finish_kernel<<<(unsigned)grid, 256, 0, s>>>(p, total8);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+// the split that brings a few-tile, deep-K problem to about one and a half workgroups per CU (1 = leave it alone)
+int ga_conv_gemm_suggest_ksplit(const ConvParams& p) {
+    if (!ga_conv_gemm_supported(p) || p.M <= 64 || p.Lout <= 0) return 1;
+    const long tiles = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase;
+    const int nsteps = (p.J * p.Cin + GBK - 1) / GBK;
+    if (tiles >= 200 || nsteps < 24) return 1;
+    long ks = (384 + tiles - 1) / tiles;
+    if (ks > nsteps / 8) ks = nsteps / 8;
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : (int)ks;
+}
+
 // ------------------------------------------------------------------------------------------------
 int ga_conv_gemm_supported(const ConvParams& p) {
     if (p.pre_act != GA_ACT_NONE) return 0;  // direct-to-LDS loads cannot transform the operand in flight
@@ -244,11 +334,13 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * 64;
     const int Ntot = p.B * p.Lout;
     const int nN = (Ntot + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const long total = (long)nN * nM * p.nphase;
-    if (total <= 0) return GA_OK;
-    if (total > (1L << 30)) return GA_ERR_ARG;
     const int Ktot = p.J * p.Cin;
     const int nsteps = (Ktot + GBK - 1) / GBK;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    if (ksplit > 1 && (!p.ws || ((uintptr_t)p.ws & 15) || ksplit > nsteps)) return GA_ERR_ARG;
+    const long total = (long)nN * nM * p.nphase * ksplit;
+    if (total <= 0) return GA_OK;
+    if (total > (1L << 30)) return GA_ERR_ARG;
     size_t lds = NBUF * (BM + BN) * 128;
     const size_t epi = 4 * 32 * (MI * 32 + 4) * sizeof(float);
     if (lds < epi) lds = epi;
@@ -274,7 +366,7 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (p.M <= 64) return nb_small == 1 ? launch_gemm<2, 1, 4, 1>(p, s) : launch_gemm<2, 1, 4, 2>(p, s);
     // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
     // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
-    const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase;
+    const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase * (p.ksplit > 1 ? p.ksplit : 1);
     int nbuf = gemm_nbuf_override();
     if (!nbuf) nbuf = blocks >= 600 ? 1 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);

@@ -132,20 +132,31 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
+    # few output tiles x deep K (D blocks 3-4): split K over workgroups, one fp32 partial-sum slab per slice
+    ks = L.lib().ga_conv_suggest_ksplit(C.byref(p), L.dt(x), impl) if SPLIT_K else 1
+    ws = None
+    if ks > 1:
+        ws = torch.empty((ks * p.B * p.LoutTot * p.M,), device=x.device, dtype=torch.float32)
+        p.ksplit, p.ws = ks, ws.data_ptr()
     if PROFILE is None:
         L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
+        if ks > 1:
+            L.check(L.lib().ga_conv_finish(C.byref(p), L.dt(x), L.stream()), "ga_conv_finish")
         return
     # benchmark accounting: HIP events on the launch stream around this one launch + its multiply-adds as launched
     kid = L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")
+    if ks > 1:
+        L.check(L.lib().ga_conv_finish(C.byref(p), L.dt(x), L.stream()), "ga_conv_finish")
     e1.record()
     PROFILE.append((kid, 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin, e0, e1,
                     (p.B, p.Cin, p.M, p.J, p.Lout, p.nphase, p.in_stride, p.pre_act)))
 
 
 _IMPL = L.IMPL_AUTO
+SPLIT_K = True  # tests switch this off to compare split-K against the single-pass kernel
 PROFILE = None  # set to a list by bench.py to collect (kernel id, launched flops, start event, end event)
 
 

@@ -75,6 +75,11 @@ typedef struct ga_conv_params {
     int phase_off0[GA_MAX_PHASE];
     int out_f32; /* bf16 problems only: write y as fp32 (no res / dact_src / accumulate); used by the STFT GEMM and the
                     decoder's waveform output so that loss arithmetic downstream sees unrounded values */
+    int ksplit;  /* > 1 (MFMA GEMM kernel only): the K = J*Cin range is divided over ksplit workgroups per output tile,
+                    each writing its partial sums to its own slab of ws; ga_conv_finish then adds the slabs and applies
+                    the epilogue (bias, act, dact, res, y).  Fills the chip when a deep-K layer has few output tiles
+                    (D blocks 3-4). */
+    float* ws;   /* split-K workspace [ksplit][B][LoutTot][M] fp32 (need not be initialised); NULL when ksplit <= 1 */
 } ga_conv_params;
 
 /* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients
@@ -83,6 +88,11 @@ typedef struct ga_conv_params {
  *   dec HF modeling_encodec.py:106 (EncodecConv1d, reflect causal pad :157-176), :193 (EncodecConvTranspose1d,
  *       right trim :206-233), called through lab3_codec_bridge.py:143 */
 int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t stream);
+/* split-K helpers (no counterpart in the reference: a scheduling detail of the same convolutions).
+ * ga_conv_suggest_ksplit: the split ga_conv would profit from for this problem (1 = do not split);
+ * ga_conv_finish: y = epi(ws) over the rows the problem covers, after a ga_conv launch with ksplit > 1. */
+int ga_conv_suggest_ksplit(const ga_conv_params* h_params, int dtype, int impl);
+int ga_conv_finish(const ga_conv_params* h_params, int dtype, ga_stream_t stream);
 
 /* which kernel ga_conv would launch for these parameters (for tests and the benchmark's per-kernel accounting) */
 #define GA_KERNEL_DIRECT_TILE 0

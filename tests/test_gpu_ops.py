@@ -172,6 +172,33 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     close(outs[L.IMPL_MFMA][1], outs[L.IMPL_DIRECT][1], 1e-2, f"{g} dgrad")
 
 
+def test_split_k_matches_single_pass():
+    """Few-tile, deep-K layers (D blocks 3-4 at the small scales) are split over K with fp32 partial sums; the result must
+    agree with the single-pass kernel to bf16 output rounding, forward (bias + LeakyReLU) and data gradient."""
+    import ctypes
+    torch.manual_seed(21)
+    for g, Ln, B in ((ConvGeom("conv", 256, 512, 41, 4, 20, 1), 469, 3), (ConvGeom("conv", 128, 256, 41, 4, 20, 1), 938, 2),
+                     (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 117, 5)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        d0, d1, k = g.wdims
+        w = torch.randn(d0, d1, k, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+        p = ops.fwd_params(g, B, Ln)
+        assert L.lib().ga_conv_suggest_ksplit(ctypes.byref(p), 1, L.IMPL_AUTO) > 1, g
+        wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+        outs = []
+        for split in (True, False):
+            ops.SPLIT_K = split
+            try:
+                outs.append((ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU).float().cpu(),
+                             ops.conv_dgrad(g, gy, wd, Ln).float().cpu()))
+            finally:
+                ops.SPLIT_K = True
+        close(outs[0][0], outs[1][0], 1e-2, f"{g} fwd")
+        close(outs[0][1], outs[1][1], 1e-2, f"{g} dgrad")
+
+
 def test_mfma_weight_gradient_matches_direct():
     """bf16 weight gradient: the gathered-GEMM MFMA kernel (direct-to-LDS loads, transposing LDS reads) and the older
     window MFMA kernel against the direct kernel on the same bf16 operands (ragged M / K / reduction tiles included)."""
