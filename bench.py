@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--prefetch", action="store_true", help="decode the next batch's frozen latents one iteration ahead on a side "
+                    "stream (gan_amd/prefetch.py; measured slower on MI355X: the two launch-bound chains do not overlap)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
     args = ap.parse_args()
 
@@ -117,9 +119,15 @@ def main():
     gen = torch.Generator().manual_seed(328 + rank)
     batches = [make_batch(args.batch, args.frames, device, gen) for _ in range(2)]
 
+    # optional (train_codec_stage(prefetch=True)): the next batch's frozen latents decoded on a side stream
+    from gan_amd.prefetch import FrozenDecodePrefetcher
+    prefetcher = FrozenDecodePrefetcher(codec) if args.prefetch else None
+
     def step(i):
         b = batches[i % len(batches)]
-        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
+        nb = batches[(i + 1) % len(batches)]
+        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp,
+                                     prefetcher=prefetcher, next_frozen=[nb[0], nb[4], nb[5]] if prefetcher else None)
 
     def barrier():
         if dp is not None:

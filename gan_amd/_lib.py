@@ -42,7 +42,7 @@ class WgradParams(C.Structure):
         ("g", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
         ("B", C.c_int), ("Lin", C.c_int), ("Cin", C.c_int), ("M", C.c_int), ("Lout", C.c_int), ("J", C.c_int),
         ("in_stride", C.c_int), ("tap_step", C.c_int), ("off0", C.c_int),
-        ("LgTot", C.c_int), ("g_stride", C.c_int), ("g_phase", C.c_int), ("rows_per_split", C.c_int),
+        ("LgTot", C.c_int), ("g_stride", C.c_int), ("g_phase", C.c_int), ("rows_per_split", C.c_int), ("ws", C.c_void_p),
     ]
 
 
@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ga_conv_suggest_ksplit": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
+    "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_unpack_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -111,6 +112,7 @@ def lib():
             fn.restype = C.c_int
         l.ga_packed_elems.argtypes = [_I, _I, _I, _I, _I]
         l.ga_packed_elems.restype = C.c_size_t
+        l.ga_wgrad_workspace_elems.restype = C.c_size_t
         l.ga_build_target.argtypes = []
         l.ga_build_target.restype = C.c_char_p
         _lib = l

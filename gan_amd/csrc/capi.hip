@@ -13,6 +13,7 @@ int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
 int ga_wgrad_gemm_supported(const WgradParams& p);
 int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s);
+size_t ga_wgrad_gemm_workspace_elems(const WgradParams& p);
 int ga_thin_conv_supported(const ConvParams& p, int dtype);
 int ga_thin_conv_impl(const ConvParams& p, int dtype, hipStream_t s);
 int ga_thin_wgrad_supported(const WgradParams& p, int dtype);
@@ -67,6 +68,12 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (p.M <= 4) return GA_KERNEL_DIRECT_FEWOUT;
     if (p.Cin == 1 && p.nphase == 1) return GA_KERNEL_DIRECT_CIN1;
     return GA_KERNEL_DIRECT_TILE;
+}
+
+size_t ga_wgrad_workspace_elems(const ga_wgrad_params* hp, int dtype, int impl) {
+    if (!hp || dtype != GA_DTYPE_BF16 || (impl != GA_IMPL_AUTO && impl != GA_IMPL_MFMA)) return 0;
+    if (ga_thin_wgrad_supported(*hp, dtype) && impl != GA_IMPL_MFMA) return 0;
+    return ga_wgrad_gemm_workspace_elems(*hp);
 }
 
 int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {

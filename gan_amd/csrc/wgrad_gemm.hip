@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
     const int s_begin = blockIdx.y * steps_per_split;
     int s_end = s_begin + steps_per_split;
     if (s_end > nsteps_total) s_end = nsteps_total;
-    if (s_begin >= s_end) return;
+    if (s_begin >= s_end && !p.ws) return;  // (slab mode: an empty slice still writes its zero tile)
 
     // staging role: instruction i covers rows i*16 + wid*4 + (lane>>4); this lane's physical 16-byte slot lane&15
     const int prow = lane >> 4;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
     }
     const bool wave_active = (mbase + wm * 64) < p.M && (kbase + wn * 64) < Ktot;
 
-    issue(0);
+    if (s_begin < s_end) issue(0);
     for (int st = s_begin; st < s_end; ++st) {
         const int buf = (st - s_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = mbase + wm * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < p.M) atomicAdd(&p.dw[(size_t)m * Ktot + k], acc[mi][ni][i]);
+                if (m < p.M) {
+                    if (p.ws) p.ws[(size_t)blockIdx.y * p.M * Ktot + (size_t)m * Ktot + k] = acc[mi][ni][i];
+                    else atomicAdd(&p.dw[(size_t)m * Ktot + k], acc[mi][ni][i]);
+                }
             }
         }
     }
@@ -170,20 +173,50 @@ int ga_wgrad_gemm_supported(const WgradParams& p) {
     return 1;
 }
 
-int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s) {
-    if (!ga_wgrad_gemm_supported(p)) return GA_ERR_ARG;
+// dw[i] += sum over slabs
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, long slab, int nslab) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ((const float4*)dw)[i];
+        for (int sidx = 0; sidx < nslab; ++sidx) {
+            const float4 v = ((const float4*)(ws + sidx * slab))[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        ((float4*)dw)[i] = a;
+    }
+}
+
+static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles) {
     const int Ktot = p.J * p.Cin;
     const long Ntot = (long)p.B * p.Lout;
-    const int mtiles = (p.M + 127) / 128, ktiles = (Ktot + 127) / 128;
-    const long base = (long)mtiles * ktiles;
-    const long nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
-    long splits = (1024 + base - 1) / base;        // aim for ~1k workgroups (4 per CU)
+    const int mtiles = (p.M + 127) / 128;
+    ktiles = (Ktot + 127) / 128;
+    base = (long)mtiles * ktiles;
+    nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
+    splits = (768 + base - 1) / base;               // aim for ~3 workgroups per CU
     const long max_splits = (nsteps + 7) / 8;       // at least 8 steps (512 rows) per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    const int sps = (int)((nsteps + splits - 1) / splits);
+    sps = (int)((nsteps + splits - 1) / splits);
     splits = (nsteps + sps - 1) / sps;
+}
+
+size_t ga_wgrad_gemm_workspace_elems(const WgradParams& p) {
+    if (!ga_wgrad_gemm_supported(p)) return 0;
+    long base, splits, nsteps;
+    int sps, ktiles;
+    wgg_plan(p, base, splits, sps, nsteps, ktiles);
+    return (size_t)splits * p.M * p.J * p.Cin;
+}
+
+int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s) {
+    if (!ga_wgrad_gemm_supported(p)) return GA_ERR_ARG;
+    const int Ktot = p.J * p.Cin;
+    const long Ntot = (long)p.B * p.Lout;
+    long base, splits, nsteps;
+    int sps, ktiles;
+    wgg_plan(p, base, splits, sps, nsteps, ktiles);
+    if (p.ws && (((uintptr_t)p.ws & 15) || ((size_t)p.M * Ktot) % 4)) return GA_ERR_ALIGN;
     const size_t lds = 4 * WGG_TILE;
     static bool attr_set = false;
     if (!attr_set) {
@@ -193,5 +226,12 @@ int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s) {
     }
     wgrad_gemm_kernel<<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
     GA_CHECK_LAUNCH();
+    if (p.ws) {
+        const long n4 = (long)p.M * Ktot / 4;
+        long grid = (n4 + 255) / 256;
+        if (grid > 4096) grid = 4096;
+        wgrad_slab_reduce_kernel<<<(unsigned)grid, 256, 0, s>>>(p.ws, p.dw, n4, (long)p.M * Ktot, (int)splits);
+        GA_CHECK_LAUNCH();
+    }
     return GA_OK;
 }

@@ -210,8 +210,11 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
                           discriminator: MultiScaleWaveDiscriminator, codec, opt_g: FusedAdamW, opt_d: FusedAdamW,
                           q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
                           q_real_tgt: Optional[torch.Tensor], q_real_tgt_g: torch.Tensor, global_step: int,
-                          noise2: Optional[torch.Tensor] = None, dp=None) -> Dict[str, torch.Tensor]:
-    """One iteration of the reference loop body (:404-591).  Returns device scalars (no host sync)."""
+                          noise2: Optional[torch.Tensor] = None, dp=None, prefetcher=None,
+                          next_frozen: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """One iteration of the reference loop body (:404-591).  Returns device scalars (no host sync).
+    prefetcher / next_frozen: see gan_amd/prefetch.py - the frozen latents of the NEXT iteration ([q_src, q_real_tgt (if
+    that iteration takes a D step), q_real_tgt_g]) are decoded on a side stream while this iteration runs."""
     device = q_src.device
     out: Dict[str, torch.Tensor] = {}
     q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
@@ -221,13 +224,18 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     # decoder is frozen and acts on every batch item independently, so one batched call gives the same waveforms with a
     # third of the (launch-bound) LSTM steps.
     B0 = int(q_src.shape[0])
-    frozen_in = torch.cat([q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g], dim=0)
-    if hasattr(codec, "decode_embeddings_mixed"):
-        x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, frozen_in)
+    frozen_list = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
+    frozen_out = prefetcher.take(frozen_list) if prefetcher is not None else None
+    if prefetcher is not None and next_frozen:
+        prefetcher.launch(next_frozen)
+    if frozen_out is not None:
+        x_hat = codec.decode_embeddings(q_hat)
+    elif hasattr(codec, "decode_embeddings_mixed"):
+        x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, torch.cat(frozen_list, dim=0))
     else:
         x_hat = codec.decode_embeddings(q_hat)
         with torch.no_grad():
-            frozen_out = codec.decode_embeddings(frozen_in)
+            frozen_out = codec.decode_embeddings(torch.cat(frozen_list, dim=0))
     with torch.no_grad():
         x_src = frozen_out[:B0]
         x_real_d_all = frozen_out[B0:2 * B0] if take_d_step else None
@@ -325,7 +333,7 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
                       discriminator: MultiScaleWaveDiscriminator, codec, lab1_encoder, style_judge, train_loader, n_genres: int,
                       style_centroid_bank: torch.Tensor, style_exemplar_bank: Optional[Dict[int, torch.Tensor]],
                       q_exemplar_bank: Dict[int, torch.Tensor], out_ckpt_dir: Path, device: torch.device, resume: bool = False,
-                      lab1_probe=None, mert_probe=None, dp=None) -> List[Dict]:
+                      lab1_probe=None, mert_probe=None, dp=None, prefetch: bool = False) -> List[Dict]:
     """reference :267-648.  Same arguments and the same 19-key history rows.  Losses are accumulated on the device and
     read back once per epoch (the reference syncs 12 scalars per iteration, :593-604)."""
     w = stage_cfg.weights
@@ -347,6 +355,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
 
     hist_rows: List[Dict] = []
     global_step = 0
+    from .prefetch import FrozenDecodePrefetcher
+    # off by default: on MI355X / ROCm 7.2 the side-stream chain was measured not to overlap with the main stream
+    prefetcher = FrozenDecodePrefetcher(codec) if (prefetch and device.type == "cuda") else None
     keys = ("loss_g", "loss_d", "loss_adv", "loss_fm", "loss_lat_l1", "loss_lat_cont", "loss_content", "loss_style",
             "loss_style_push", "loss_delta_budget", "loss_mrstft", "loss_ms")
     for epoch in range(start_epoch + 1, int(stage_cfg.epochs) + 1):
@@ -356,11 +367,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             alpha += (float(stage_cfg.cond_alpha_end) - float(stage_cfg.cond_alpha_start)) * ratio
         acc = {k: torch.zeros((), device=device) for k in keys}
         d_steps_taken = d_steps_skipped = n_batches = 0
-        for bi, batch in enumerate(train_loader):
-            if stage_cfg.max_batches_per_epoch is not None and bi >= int(stage_cfg.max_batches_per_epoch):
-                break
-            global_step += 1
-            n_batches += 1
+        def prepare(bi, batch, step):
+            """Everything one iteration draws or moves (the reference's :361-421,455-457), so that it can be done one batch
+            ahead: the next batch's frozen latents go to the side-stream decode while the current iteration runs."""
             q_src = batch["q_emb"].to(device, non_blocking=True).float()
             zc_src = F.normalize(batch["z_content"].to(device, non_blocking=True).float(), dim=-1)
             zs_src = F.normalize(batch["z_style"].to(device, non_blocking=True).float(), dim=-1)
@@ -377,11 +386,34 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
                     and int(z_style_tgt.shape[1]) == int(zs_src.shape[1])):
                 z_style_tgt = zs_src
             noise = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
-            take_d = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
+            take_d = (step % max(1, int(stage_cfg.d_step_period))) == 0
             q_real_tgt = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float() if take_d else None
             q_real_tgt_g = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float()
-            res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, q_src, zc_src, z_style_tgt,
-                                        noise, q_real_tgt, q_real_tgt_g, global_step, dp=dp)
+            return dict(q_src=q_src, zc_src=zc_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, q_real_tgt=q_real_tgt,
+                        q_real_tgt_g=q_real_tgt_g, step=step)
+
+        def frozen_of(item):
+            return [item["q_src"]] + ([item["q_real_tgt"]] if item["take_d"] else []) + [item["q_real_tgt_g"]]
+
+        def batches():
+            for bi, batch in enumerate(train_loader):
+                if stage_cfg.max_batches_per_epoch is not None and bi >= int(stage_cfg.max_batches_per_epoch):
+                    return
+                yield bi, batch
+
+        it = batches()
+        nxt = next(it, None)
+        cur = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
+        while cur is not None:
+            global_step += 1
+            n_batches += 1
+            nxt = next(it, None)
+            ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
+            take_d = cur["take_d"]
+            res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, cur["q_src"], cur["zc_src"],
+                                        cur["z_style_tgt"], cur["noise"], cur["q_real_tgt"], cur["q_real_tgt_g"], global_step,
+                                        dp=dp, prefetcher=prefetcher, next_frozen=frozen_of(ahead) if ahead is not None else None)
+            cur = ahead
             if take_d:
                 d_steps_taken += 1
             else:

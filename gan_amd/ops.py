@@ -156,6 +156,7 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
 
 
 _IMPL = L.IMPL_AUTO
+WGRAD_SLABS = False  # True: per-slice slabs + a reduce kernel instead of fp32 atomics on dw (measured no faster; tests run both)
 SPLIT_K = True  # tests switch this off to compare split-K against the single-pass kernel
 PROFILE = None  # set to a list by bench.py to collect (kernel id, launched flops, start event, end event)
 
@@ -210,6 +211,10 @@ def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
     db = torch.zeros((g.cout,), device=x.device, dtype=torch.float32) if want_bias else None
     _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=L.ptr(db), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout,
           Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
+    nws = L.lib().ga_wgrad_workspace_elems(C.byref(p), L.dt(x), _IMPL) if WGRAD_SLABS else 0
+    if nws:
+        ws = torch.empty((nws,), device=x.device, dtype=torch.float32)  # per-slice partial tiles (plain stores, no atomics)
+        p.ws = ws.data_ptr()
     L.check(L.lib().ga_wgrad(C.byref(p), L.dt(x), _IMPL, L.stream()), "ga_wgrad")
     return (dw, db) if want_bias else dw
 

@@ -119,8 +119,13 @@ typedef struct ga_wgrad_params {
     int B, Lin, Cin, M, Lout, J, in_stride, tap_step, off0;
     int LgTot, g_stride, g_phase;
     int rows_per_split; /* set by the library */
+    float* ws;          /* optional workspace of ga_wgrad_workspace_elems() floats (need not be initialised): the slices of
+                           the reduction range then write their partial tiles as plain stores to slabs that one more
+                           kernel adds into dw, instead of fp32 atomics on dw; NULL = atomics */
 } ga_wgrad_params;
 int ga_wgrad(const ga_wgrad_params* h_params, int dtype, int impl, ga_stream_t stream);
+/* floats of workspace ga_wgrad can use for this problem (0: the kernel it would pick has no slab path) */
+size_t ga_wgrad_workspace_elems(const ga_wgrad_params* h_params, int dtype, int impl);
 
 /* weight norm (torch.nn.utils.weight_norm, dim=0: lab3_codec_models.py:125,143; parametrizations.weight_norm in the
  * HF decoder, modeling_encodec.py:109-111,196-201): scale[r] = g[r]/||v[r,:]||, norm[r] = ||v[r,:]|| */

@@ -217,6 +217,13 @@ def test_mfma_weight_gradient_matches_direct():
             finally:
                 ops.set_conv_impl(L.IMPL_AUTO)
         close(outs[0], outs[1].cpu(), 2e-3, f"wgrad {g}")
+        ops.set_conv_impl(L.IMPL_MFMA)
+        ops.WGRAD_SLABS = True
+        try:
+            close(ops.conv_wgrad(g, ga, x), outs[1].cpu(), 2e-3, f"slab wgrad {g}")
+        finally:
+            ops.WGRAD_SLABS = False
+            ops.set_conv_impl(L.IMPL_AUTO)
         if g.cin >= 32 and g.cin % 8 == 0 and g.cout % 8 == 0 and B * g.out_len(Ln) >= 256:
             ops.set_conv_impl(L.IMPL_MFMA_WINDOW)
             try:
