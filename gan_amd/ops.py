@@ -207,8 +207,10 @@ def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
     assert ga.is_contiguous() and x.is_contiguous() and ga.dtype == x.dtype
     B, lout, cout = ga.shape
     p = L.WgradParams()
-    dw = torch.zeros((g.cout, g.k, g.cin), device=x.device, dtype=torch.float32)
-    db = torch.zeros((g.cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    ndw = g.cout * g.k * g.cin
+    buf = torch.zeros((ndw + (g.cout if want_bias else 0),), device=x.device, dtype=torch.float32)  # one fill for both
+    dw = buf[:ndw].view(g.cout, g.k, g.cin)
+    db = buf[ndw:] if want_bias else None
     _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=L.ptr(db), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout,
           Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
     nws = L.lib().ga_wgrad_workspace_elems(C.byref(p), L.dt(x), _IMPL) if WGRAD_SLABS else 0
@@ -242,6 +244,45 @@ def wn_scale(v: Tensor, gparam: Tensor) -> Tuple[Tensor, Tensor]:
     return scale, norm
 
 
+# ---- packed-weight cache -------------------------------------------------------------------------
+# A trainable layer's packed weights only change when its optimizer steps (a raw-pointer kernel torch's version counters
+# do not see) or when torch writes the parameter in place (which they do see).  FusedAdamW registers the address range of
+# its flat parameter buffer with an epoch it bumps on every step, so a pack made in the G step (after D's update) is
+# reused by the next iteration's D step instead of being rebuilt from the fp32 masters.
+_EPOCH_RANGES: list = []   # (lo, hi, [epoch])
+_PACK_CACHE: dict = {}
+PACK_CACHE = True
+
+
+def register_param_range(lo: int, hi: int) -> list:
+    global _EPOCH_RANGES
+    _EPOCH_RANGES = [r for r in _EPOCH_RANGES if r[1] <= lo or r[0] >= hi]  # address reuse by a new optimizer
+    stale = [k for k in _PACK_CACHE if lo <= k[0] < hi]
+    for k in stale:
+        del _PACK_CACHE[k]
+    holder = [0]
+    _EPOCH_RANGES.append((lo, hi, holder))
+    return holder
+
+
+def _epoch_holder(ptr: int):
+    for lo, hi, h in _EPOCH_RANGES:
+        if lo <= ptr < hi:
+            return h
+    return None
+
+
+_ZERO1: dict = {}
+
+
+def _zero_scalar(device) -> Tensor:
+    """One shared fp32 zero per device (never written): the storage behind every expanded gradient carrier."""
+    z = _ZERO1.get(device)
+    if z is None:
+        z = _ZERO1[device] = torch.zeros((1,), device=device, dtype=torch.float32)
+    return z
+
+
 class PackTrainable(torch.autograd.Function):
     """(v, g | None) -> (forward pack, data-gradient pack) in the activation dtype.  Backward takes the
     packed-forward-layout gradient from the weight-gradient kernel back to the parameter layout and through
@@ -250,18 +291,33 @@ class PackTrainable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, gparam, geom: ConvGeom, dtype):
         v = v.contiguous()
-        scale = norm = None
-        if gparam is not None:
-            scale, norm = wn_scale(v, gparam.contiguous())
-        wp_f = pack_weight(geom, v, geom.fwd_pack, dtype, scale)
-        wp_d = pack_weight(geom, v, geom.dgrad_pack, dtype, scale)
+        key = (v.data_ptr(), geom, dtype)
+        holder = _epoch_holder(v.data_ptr()) if PACK_CACHE else None
+        stamp = None
+        if holder is not None:
+            stamp = (holder[0], v._version, None if gparam is None else (gparam.data_ptr(), gparam._version))
+            hit = _PACK_CACHE.get(key)
+            if hit is not None and hit[0] == stamp:
+                _, wp_f, wp_d, norm = hit
+            else:
+                hit = None
+        else:
+            hit = None
+        if hit is None:
+            scale = norm = None
+            if gparam is not None:
+                scale, norm = wn_scale(v, gparam.contiguous())
+            wp_f = pack_weight(geom, v, geom.fwd_pack, dtype, scale)
+            wp_d = pack_weight(geom, v, geom.dgrad_pack, dtype, scale)
+            if holder is not None:
+                _PACK_CACHE[key] = (stamp, wp_f, wp_d, norm)
         ctx.geom = geom
         ctx.has_g = gparam is not None
         ctx.save_for_backward(v, gparam, norm)
         ctx.mark_non_differentiable(wp_f, wp_d)
         # fp32 gradient carrier: autograd casts a gradient to the dtype of the tensor it belongs to, so the
         # fp32 weight gradient cannot travel on the (possibly bf16) packed weights themselves.
-        carrier = torch.zeros((1,), device=v.device, dtype=torch.float32).expand(wp_f.numel())
+        carrier = _zero_scalar(v.device).expand(wp_f.numel())
         return wp_f, wp_d, carrier
 
     @staticmethod
@@ -414,9 +470,11 @@ class GnFilmAct(torch.autograd.Function):
         dy = dy.contiguous()
         B, T, Cn = x.shape
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(beta)
-        dab = torch.zeros_like(ab) if ab is not None else None
+        nab = ab.numel() if ab is not None else 0
+        zbuf = torch.zeros((2 * gamma.numel() + nab,), device=gamma.device, dtype=torch.float32)  # one fill for all three
+        dgamma = zbuf[:gamma.numel()].view_as(gamma)
+        dbeta = zbuf[gamma.numel():2 * gamma.numel()].view_as(beta)
+        dab = zbuf[2 * gamma.numel():].view_as(ab) if ab is not None else None
         L.check(L.lib().ga_gn_film_act_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                            beta.data_ptr(), L.ptr(ab), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                            L.ptr(dab), L.dt(x), B, T, Cn, ctx.groups, ctx.act, L.stream()), "ga_gn_film_act_bwd")

@@ -45,6 +45,8 @@ class FusedAdamW:
                 view.copy_(p.data)
                 p.data = view
         self.grad_views = [self.flat_g[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
+        from . import ops
+        self._epoch = ops.register_param_range(self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * n)  # packed-weight cache
         self.last_grad_norm: Optional[torch.Tensor] = None
         self.grad_scale = 1.0  # 1/world_size when flat_g holds a SUM over ranks
 
@@ -70,6 +72,7 @@ class FusedAdamW:
         if not grads_gathered:
             self.gather_grads()
         self.step_count += 1
+        self._epoch[0] += 1  # the parameters change under a raw pointer: invalidate cached packs
         lib = L.lib()
         self._sq.zero_()
         L.check(lib.ga_grad_sqnorm(self.flat_g.data_ptr(), self.numel, self._sq.data_ptr(), L.stream()), "ga_grad_sqnorm")
