@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--prefetch", action="store_true", help="decode the next batch's frozen latents one iteration ahead on a side "
                     "stream (gan_amd/prefetch.py; measured slower on MI355X: the two launch-bound chains do not overlap)")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
     args = ap.parse_args()
 
@@ -98,9 +99,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dp = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # --force-dp outside torchrun: a one-rank RCCL group
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
         from gan_amd.dp import DataParallel
         dp = DataParallel()
 

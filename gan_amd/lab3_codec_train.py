@@ -121,7 +121,7 @@ def _sample_bank_rows(bank: Dict[int, torch.Tensor], labels: torch.Tensor, devic
 def _mix_style_condition(target_idx: torch.Tensor, cond_mode: str, alpha: float, centroid_bank: torch.Tensor,
                          exemplar_bank: Optional[Dict[int, torch.Tensor]], device: torch.device,
                          exemplar_noise_std: float) -> torch.Tensor:
-    z_cent = centroid_bank[target_idx].to(device)
+    z_cent = centroid_bank[target_idx.to(centroid_bank.device)].to(device)
     if exemplar_bank is None or len(exemplar_bank) == 0:
         z_ex = z_cent
     else:
@@ -373,7 +373,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             q_src = batch["q_emb"].to(device, non_blocking=True).float()
             zc_src = F.normalize(batch["z_content"].to(device, non_blocking=True).float(), dim=-1)
             zs_src = F.normalize(batch["z_style"].to(device, non_blocking=True).float(), dim=-1)
-            src_genre_idx = batch["genre_idx"].to(device, non_blocking=True).long()
+            # labels stay on the host: target / exemplar sampling reads them row by row (reference :109-118), and a
+            # device tensor there would cost a stream-draining .cpu() per draw
+            src_genre_idx = batch["genre_idx"].detach().to("cpu").long()
             if str(stage_cfg.stage_name) == "stage1":
                 tgt_genre_idx = src_genre_idx
             elif bool(stage_cfg.target_balance):
