@@ -28,6 +28,8 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     const ConvParams& p = *hp;
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
+    if (p.y_batch_elems != 0 && !(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return GA_ERR_ARG;
+    if (p.y_batch_elems != 0) return ga_conv_gemm_impl(p, s);
     if (p.ksplit > 1) return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_MFMA_WINDOW) return can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_MFMA) return can_gemm ? ga_conv_gemm_impl(p, s) : can_mfma ? ga_conv_mfma_impl(p, s) : GA_ERR_ARG;

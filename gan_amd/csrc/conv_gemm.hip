@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     constexpr int RPP = 64 / LPR;       // rows per pass
     const int erow = lane / LPR, ec8 = (lane % LPR) * 8;
     const int m0 = mbase + wm * WMR + ec8;
+    const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -182,12 +183,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
             const int b = n / p.Lout, t = p.t0 + (n - b * p.Lout);
             const int orow = t * p.out_stride + phase;
             if (orow < 0 || orow >= p.LoutTot) continue;
-            const size_t o = ((size_t)b * p.LoutTot + orow) * p.M + m0;
+            const size_t in_item = (size_t)orow * p.M + m0;
+            if (in_item + 8 > item_elems) continue;  // (folded phases: the last row may run past the item)
+            const size_t o = (size_t)b * item_elems + in_item;
             float v[8];
             *(float4*)&v[0] = *(const float4*)(stage + row * EPF + ec8);
             *(float4*)&v[4] = *(const float4*)(stage + row * EPF + ec8 + 4);
             if (ksplit > 1) {  // partial sums only, into this slice's own slab; ga_conv_finish adds the slabs and applies the epilogue
-                float* wo = p.ws + (size_t)split * ((size_t)p.B * p.LoutTot * p.M) + o;
+                float* wo = p.ws + (size_t)split * ((size_t)p.B * item_elems) + o;
                 *(float4*)wo = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(wo + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 continue;
@@ -240,9 +243,12 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, long tot
         const int tl = (int)(row % p.Lout), b = (int)(row / p.Lout);
         const int orow = (p.t0 + tl) * p.out_stride + phase;
         if (orow < 0 || orow >= p.LoutTot) continue;
-        const size_t o = ((size_t)b * p.LoutTot + orow) * p.M + m0;
+        const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
+        const size_t in_item = (size_t)orow * p.M + m0;
+        if (in_item + 8 > item_elems) continue;
+        const size_t o = (size_t)b * item_elems + in_item;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const size_t slab = (size_t)p.B * p.LoutTot * p.M;
+        const size_t slab = (size_t)p.B * item_elems;
         for (int sp = 0; sp < p.ksplit; ++sp) {
             const float4 a0 = *(const float4*)(p.ws + sp * slab + o), a1 = *(const float4*)(p.ws + sp * slab + o + 4);
             v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
@@ -313,6 +319,7 @@ int ga_conv_gemm_supported(const ConvParams& p) {
     if (p.pre_act != GA_ACT_NONE) return 0;  // direct-to-LDS loads cannot transform the operand in flight
     if (p.Cin % 8 || p.Cin < 8 || p.M % 8 || p.M < 16 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
     if (p.nphase < 1 || p.nphase > GA_MAX_PHASE) return 0;
+    if (p.y_batch_elems < 0 || (p.y_batch_elems > 0 && (p.y_batch_elems % 8 || (long)p.y_batch_elems > (long)p.LoutTot * p.M))) return 0;
     if (p.out_f32 && (p.res || p.dact_src || p.accumulate)) return 0;
     if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
     if ((long)p.J * p.Cin > (1L << 30) || (long)p.B * p.Lout > (1L << 30)) return 0;

@@ -132,6 +132,8 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
+    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA):
+        p, bias = _fold_phases(p, x, bias)
     # few output tiles x deep K (D blocks 3-4): split K over workgroups, one fp32 partial-sum slab per slice
     ks = L.lib().ga_conv_suggest_ksplit(C.byref(p), L.dt(x), impl) if SPLIT_K else 1
     ws = None
@@ -155,6 +157,47 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
                     (p.B, p.Cin, p.M, p.J, p.Lout, p.nphase, p.in_stride, p.pre_act)))
 
 
+_BIAS_REP: dict = {}
+
+
+def _fold_phases(p: L.ConvParams, x: Tensor, bias):
+    """Output phases folded into the channel dimension.  A strided conv's data gradient and a transposed conv's forward
+    are `nphase` problems that read the SAME input rows (all phase offsets equal) with different weight slices and write
+    interleaved output rows; since y[t*S + r][m] is element (r*M + m) of a row of S*M channels, they are also ONE problem
+    with M' = S*M, out_stride 1 and the packed weights unchanged ([S][M][J][Cin] == [S*M][J][Cin]).  One pass over the
+    input instead of S, and 128-wide tiles for the 32/64-channel layers.  Only the MFMA GEMM kernel has the per-item
+    element bound this needs when the item length is not a multiple of S."""
+    S = int(p.nphase)
+    if S <= 1 or p.out_stride != S or p.t0 != 0 or x.dtype != torch.bfloat16 or p.ksplit > 1:
+        return p, bias
+    if any(p.phase_off0[r] != p.phase_off0[0] for r in range(S)):
+        return p, bias
+    q = L.ConvParams()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(L.ConvParams))
+    q.M = p.M * S
+    q.nphase, q.out_stride = 1, 1
+    q.off0 = p.off0 + p.phase_off0[0]
+    for r in range(L.GA_MAX_PHASE):
+        q.phase_off0[r] = 0
+    q.LoutTot = (p.LoutTot + S - 1) // S
+    q.y_batch_elems = p.LoutTot * p.M
+    if q.y_batch_elems % 8 or q.y_batch_elems >= 2 ** 31:
+        return p, bias
+    if bias is not None:
+        # cache entries hold the bias tensor itself, so neither its id nor its address can be reused while cached
+        key = (id(bias), S)
+        ent = _BIAS_REP.get(key)
+        if ent is None or ent[0] is not bias or ent[1] != bias._version:
+            if len(_BIAS_REP) > 256:
+                _BIAS_REP.clear()
+            ent = _BIAS_REP[key] = (bias, bias._version, bias.detach().repeat(S).contiguous())
+        q.bias = ent[2].data_ptr()
+    if L.lib().ga_conv_kernel_id(C.byref(q), L.dt(x), L.IMPL_MFMA) not in L.GEMM_KERNELS:
+        return p, bias
+    return q, bias
+
+
+MERGE_PHASES = True  # tests switch this off to compare against the phase-by-phase launches
 _IMPL = L.IMPL_AUTO
 WGRAD_SLABS = False  # True: per-slice slabs + a reduce kernel instead of fp32 atomics on dw (measured no faster; tests run both)
 SPLIT_K = True  # tests switch this off to compare split-K against the single-pass kernel

@@ -80,6 +80,10 @@ typedef struct ga_conv_params {
                     the epilogue (bias, act, dact, res, y).  Fills the chip when a deep-K layer has few output tiles
                     (D blocks 3-4). */
     float* ws;   /* split-K workspace [ksplit][B][LoutTot][M] fp32 (need not be initialised); NULL when ksplit <= 1 */
+    int y_batch_elems; /* 0: batch items of y / res / dact_src are LoutTot*M elements apart.  Otherwise (MFMA GEMM kernel
+                    only) that distance AND the number of valid elements per item: lets the output phases of a strided
+                    data gradient / transposed conv be folded into M (rows of nphase*M channels, which is the same
+                    memory as nphase rows of M) when the item length is not a multiple of nphase */
 } ga_conv_params;
 
 /* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients

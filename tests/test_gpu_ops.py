@@ -172,6 +172,33 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     close(outs[L.IMPL_MFMA][1], outs[L.IMPL_DIRECT][1], 1e-2, f"{g} dgrad")
 
 
+def test_folded_phases_match_phase_by_phase():
+    """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
+    (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
+    multiple of S (the per-item element bound)."""
+    torch.manual_seed(31)
+    for g, Ln, B in ((ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 2), (ConvGeom("conv", 128, 256, 41, 4, 20, 1), 1875, 2),
+                     (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 470, 3), (ConvGeom("convt", 128, 64, 8, 4), 301, 2),
+                     (ConvGeom("convt", 64, 32, 4, 2), 777, 3), (ConvGeom("convt", 512, 256, 16, 8), 40, 2)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        d0, d1, k = g.wdims
+        w = torch.randn(d0, d1, k, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+        wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+        outs = []
+        for merge in (True, False):
+            ops.MERGE_PHASES = merge
+            try:
+                if g.kind == "convt":
+                    outs.append(ops.conv_forward(g, x, wf, bias).float().cpu())
+                else:
+                    outs.append(ops.conv_dgrad(g, gy, wd, Ln).float().cpu())
+            finally:
+                ops.MERGE_PHASES = True
+        close(outs[0], outs[1], 1e-2, f"{g} L={Ln}")
+
+
 def test_split_k_matches_single_pass():
     """Few-tile, deep-K layers (D blocks 3-4 at the small scales) are split over K with fp32 partial sums; the result must
     agree with the single-pass kernel to bf16 output rounding, forward (bias + LeakyReLU) and data gradient."""
