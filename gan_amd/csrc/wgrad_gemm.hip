@@ -111,7 +111,12 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
 
     // transposed-read addressing: row = kk*16 + 8h + q (+4), columns 16*(g4&1) + 4*pp .. +3 of the wave's 32-column
     // fragment; element column e -> logical piece e>>3, byte (e&7)*2; physical piece = logical ^ ((row&3)<<2), row&3 == q
-    const int ecolA[2] = {wm * 64 + 16 * (g4 & 1) + 4 * pp, wm * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
+    // M <= 64: only the first 64 rows of the 128-row tile exist.  Instead of idling, waves wm = 1 take the second half
+    // of every 64-row reduction step for the SAME 64 x 64 output sub-tile (the partial sums meet in the atomics).
+    const bool halfm = p.M <= 64;
+    const int wme = halfm ? 0 : wm;
+    const int kk0 = halfm ? wm * 2 : 0, kk1 = halfm ? wm * 2 + 2 : 4;
+    const int ecolA[2] = {wme * 64 + 16 * (g4 & 1) + 4 * pp, wme * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
     const int ecolB[2] = {wn * 64 + 16 * (g4 & 1) + 4 * pp, wn * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
     int offA[2], offB[2];
 #pragma unroll
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
         offA[i] = ((((ecolA[i] >> 3) ^ (q << 2)) << 4) | ((ecolA[i] & 7) << 1)) + (8 * h + q) * 256;
         offB[i] = ((((ecolB[i] >> 3) ^ (q << 2)) << 4) | ((ecolB[i] & 7) << 1)) + (8 * h + q) * 256;
     }
-    const bool wave_active = (mbase + wm * 64) < p.M && (kbase + wn * 64) < Ktot;
+    const bool wave_active = (mbase + wme * 64) < p.M && (kbase + wn * 64) < Ktot;
 
     if (s_begin < s_end) issue(0);
     for (int st = s_begin; st < s_end; ++st) {
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
             const char* Bb = Bl + buf * WGG_TILE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
+                if (kk < kk0 || kk >= kk1) continue;
                 bf16x8 a[2], b[2];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) a[mi] = wg_tr_frag(Ab + kk * 4096 + offA[mi], Ab + kk * 4096 + offA[mi] + 1024);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = mbase + wm * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int m = mbase + wme * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (m < p.M) {
                     if (p.ws) p.ws[(size_t)blockIdx.y * p.M * Ktot + (size_t)m * Ktot + k] = acc[mi][ni][i];
                     else atomicAdd(&p.dw[(size_t)m * Ktot + k], acc[mi][ni][i]);
@@ -202,15 +208,17 @@ static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, l
 }
 
 size_t ga_wgrad_gemm_workspace_elems(const WgradParams& p) {
-    if (!ga_wgrad_gemm_supported(p)) return 0;
+    if (!ga_wgrad_gemm_supported(p) || p.M <= 64) return 0;  // (M <= 64: two waves share an output sub-tile: atomics only)
     long base, splits, nsteps;
     int sps, ktiles;
     wgg_plan(p, base, splits, sps, nsteps, ktiles);
     return (size_t)splits * p.M * p.J * p.Cin;
 }
 
-int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s) {
-    if (!ga_wgrad_gemm_supported(p)) return GA_ERR_ARG;
+int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
+    if (!ga_wgrad_gemm_supported(p_in)) return GA_ERR_ARG;
+    WgradParams p = p_in;
+    if (p.M <= 64) p.ws = nullptr;
     const int Ktot = p.J * p.Cin;
     const long Ntot = (long)p.B * p.Lout;
     long base, splits, nsteps;
