@@ -445,6 +445,40 @@ __global__ void act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ s
         for (size_t i = nv * EV; i < n; ++i) ga[i] = (T)((float)gy[i] * dact_apply(mode, (float)src[i]));
 }
 
+// ga = gy * act'(src) AND dbias[m] += sum_rows ga[row][m] in the same pass (rows of M channels, M/EV a divisor of 256, so a
+// thread keeps the same EV channels for every row it visits: partial sums live in registers, one LDS reduction per block)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__ gy, const T* __restrict__ src, T* __restrict__ ga,
+                                                            size_t nv, int mode, int M, float* __restrict__ dbias) {
+    constexpr int EV = 16 / sizeof(T);
+    __shared__ float red[256][EV + 1];
+    const int MV = M / EV;
+    float acc[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) acc[e] = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        const Pack16<T> a = ((const Pack16<T>*)gy)[i], b = ((const Pack16<T>*)src)[i];
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            const float v = (float)a.v[e] * dact_apply(mode, (float)b.v[e]);
+            o.v[e] = (T)v;
+            acc[e] += (float)o.v[e];  // the rounded value: what the weight-gradient kernel will see
+        }
+        ((Pack16<T>*)ga)[i] = o;
+    }
+#pragma unroll
+    for (int e = 0; e < EV; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    // thread tid owns vector column (tid % MV) for all of its rows (gridDim.x * 256 is a multiple of MV)
+    for (int o = threadIdx.x; o < M; o += 256) {
+        const int col = o / EV, e = o % EV;
+        float sacc = 0.f;
+        for (int t = col; t < 256; t += MV) sacc += red[t][e];
+        atomicAdd(&dbias[o], sacc);
+    }
+}
+
 // y = act(x)
 template <typename T>
 __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, int act) {
@@ -793,6 +827,19 @@ int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, i
     const int grid = grid_for(n / 4 + 1, 256, 4096);
     DISPATCH_T(dtype, (act_bwd_kernel<float><<<grid, 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, n, mode)),
                (act_bwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, n, mode)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_act_bwd_bias(const void* gy, const void* src, void* ga, int dtype, size_t rows, int M, int mode, float* dbias, hipStream_t s) {
+    if (!gy || !src || !ga || !dbias || M <= 0) return GA_ERR_ARG;
+    if (((uintptr_t)gy | (uintptr_t)src | (uintptr_t)ga) & 15) return GA_ERR_ALIGN;
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    if (M % ev || 256 % (M / ev)) return GA_ERR_ARG;
+    const size_t nv = rows * (size_t)(M / ev);
+    const int grid = grid_for(nv, 256, 2048);
+    DISPATCH_T(dtype, (act_bwd_bias_kernel<float><<<grid, 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, nv, mode, M, dbias)),
+               (act_bwd_bias_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, nv, mode, M, dbias)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -423,13 +423,23 @@ class ConvTrain(torch.autograd.Function):
         x, wp_d, y = ctx.saved_tensors
         geom = ctx.geom
         gy = gy.contiguous()
-        ga = act_bwd(gy, y, L.DACT_LRELU_FROM_OUT) if ctx.post_act == L.ACT_LRELU else gy
         if ctx.post_act not in (L.ACT_NONE, L.ACT_LRELU):
             raise NotImplementedError("ConvTrain supports LeakyReLU or no activation")
+        want_b = ctx.has_bias and ctx.needs_input_grad[4]
         gx = gw = gb = None
+        M = gy.shape[-1]
+        ev = 8 if gy.dtype == torch.bfloat16 else 4
+        if ctx.post_act == L.ACT_LRELU and want_b and M % ev == 0 and 256 % (M // ev) == 0:
+            # mask and bias gradient in one pass over gy
+            ga = torch.empty_like(gy)
+            gb = torch.zeros((M,), device=gy.device, dtype=torch.float32)
+            L.check(L.lib().ga_act_bwd_bias(gy.data_ptr(), y.data_ptr(), ga.data_ptr(), L.dt(gy), gy.numel() // M, M,
+                                            L.DACT_LRELU_FROM_OUT, gb.data_ptr(), L.stream()), "ga_act_bwd_bias")
+            want_b = False
+        else:
+            ga = act_bwd(gy, y, L.DACT_LRELU_FROM_OUT) if ctx.post_act == L.ACT_LRELU else gy
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(geom, ga, wp_d, x.shape[1])
-        want_b = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
             if want_b:
                 gw, gb = conv_wgrad(geom, ga, x, want_bias=True)

@@ -173,6 +173,10 @@ int ga_avgpool1d_bwd(const void* dy, void* dx, int dtype, int B, int L, int Lo, 
 
 /* ga = gy * act'(src): backward of leaky_relu (lab3_codec_models.py:128) */
 int ga_act_bwd(const void* gy, const void* src, void* ga, int dtype, size_t n, int mode, ga_stream_t stream);
+/* the same on [rows][M] plus the conv bias gradient dbias[m] += sum_rows ga[row][m] in one pass (caller zeroes dbias);
+ * M / (16 bytes of elements) must divide 256 */
+int ga_act_bwd_bias(const void* gy, const void* src, void* ga, int dtype, size_t rows, int M, int mode, float* dbias,
+                    ga_stream_t stream);
 /* y = act(x), elementwise (GA_ACT_*): the ELU in front of every SEANet decoder conv (modeling_encodec.py:265-275,
  * 330-343), materialised once so that the conv itself can stream its operand straight into LDS */
 int ga_act_fwd(const void* x, void* y, int dtype, size_t n, int act, ga_stream_t stream);
