@@ -75,4 +75,6 @@ class DataParallel:
     def broadcast_params(self, *opts) -> None:
         for opt in opts:
             dist.broadcast(opt.flat_p, src=0, group=self.group)
-            opt._epoch[0] += 1  # parameters rewritten in place: cached weight packs are stale
+            epoch = getattr(opt, "_epoch", None)
+            if epoch is not None:
+                epoch[0] += 1  # parameters rewritten in place: cached weight packs are stale
