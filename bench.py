@@ -73,6 +73,26 @@ def cpu_baseline(T: int, sample_B: int, iters: int):
                       f"{dt:.2f} s/iteration"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
+    scratch/pmc_traffic.py from two rocprofv3 --pmc passes over this same command: FETCH_SIZE x2 and WRITE_SIZE, both KiB, as
+    MI355X_MICROARCH.md's HBM section prescribes).  PMC counters cannot be read from inside the process, so the figure is
+    the last profiled build's; `traffic_source` names the file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel_name)
+    except (OSError, ValueError, KeyError):
+        return {}
+    if not k:
+        return {}
+    return {"traffic": round(k["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,11 +190,15 @@ def main():
             print("kernel  (B, Cin, M, J, Lout, nphase, in_stride, pre_act)  launches  ms  TFLOP/s", file=sys.stderr)
             for key, r in sorted(rows.items(), key=lambda kv: -kv[1][2]):
                 print(f"{KERNEL_NAMES[key[0]]:26s} {str(key[1:]):44s} {r[0]:3d} {r[2]:8.3f} {r[1] / max(r[2], 1e-9) / 1e9:8.1f}", file=sys.stderr)
-        for kid, flops, e0, e1, _shape in prof:
-            k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        esz = 2 if args.precision == "bf16" else 4
+        for kid, flops, e0, e1, shape in prof:
+            k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             k["launches"] += 1
             k["flops"] += flops
             k["ms"] += e0.elapsed_time(e1)
+            b_, cin_, m_, j_, lout_, _nph, istr_ = shape[:7]
+            # algorithmic bytes of one launch: the input window once, the packed weights once, the output once
+            k["bytes"] += esz * (b_ * lout_ * max(1, istr_) * cin_ + m_ * j_ * cin_ + b_ * lout_ * m_)
         dom = max((k for k in kernels if k in (3, 4, 7, 8, 9)), key=lambda k: kernels[k]["ms"], default=None)
         if dom is not None:
             k = kernels[dom]
@@ -182,7 +206,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
-                        "flops_per_launch_avg": k["flops"] / k["launches"]}
+                        "flops_per_launch_avg": k["flops"] / k["launches"],
+                        "algorithmic_bytes_per_launch_avg": k["bytes"] / k["launches"]}
+            roofline.update(pmc_traffic(KERNEL_NAMES[dom]))
 
     if rank == 0:
         total_samples = args.batch * world * args.steps
