@@ -1,0 +1,283 @@
+// bf16 MFMA "streaming" kernel for the thin layers of the generalised NLC convolution (gfx950):
+// M <= 64 output channels and K = J*Cin <= 192.  These layers (the 16..64-channel end of the SEANet decoder at
+// 60000..120000 samples per item, and their data gradients) move 200-550 MB per launch for a few GFLOP: they are
+// HBM-bound, and what limits a tiled GEMM on them is bytes in flight per CU, not arithmetic.
+//
+//   * the packed weights (<= 24 KiB) live in registers as MFMA A fragments for the whole launch
+//   * the B operand needs no LDS: in channels-last layout the fragment of v_mfma_f32_32x32x16_bf16 that lane (n, h)
+//     supplies -- 8 consecutive k of im2col row n -- is 16 contiguous bytes of x (one tap, 8 channels), loaded
+//     straight from global memory into the operand registers (padding reads a 16-byte zero page)
+//   * every wave walks groups of NT*32 rows of the flattened (item, step) axis, grid-stride; per trip it issues, in this
+//     order and with no branch around any load, the residual / derivative-source pieces of the CURRENT group and the x
+//     fragments of the NEXT group, then multiplies and stores the current group: the memory counter is in-order, so the
+//     waits the compiler places leave the next group's loads in flight behind the current group's epilogue
+//   * the input activation (ELU in front of every decoder conv, HF modeling_encodec.py:268,330,340) is applied to
+//     the fragments in registers, so no act(x) copy is written and read back
+//   * epilogue: accumulators -> wave-private LDS rows -> 16-byte row-contiguous global accesses
+// Epilogue variants are compile-time (SIDE: none / residual / derivative source) so that the loop stays small and
+// branch-free; other combinations (accumulate, fp32 output, residual AND derivative) stay with conv_gemm.hip.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define STREAM_KMAX 192
+#define SIDE_NONE 0
+#define SIDE_RES 1
+#define SIDE_DACT 2
+
+// loads through an integer-selected address must say "global": a generic pointer becomes flat_load, whose waits drain
+// both counters to zero and serialise the pipeline
+typedef const __attribute__((address_space(1))) bf16x8* gfrag_ptr_t;
+__device__ __forceinline__ bf16x8 ldg_frag(uintptr_t a) { return *(gfrag_ptr_t)a; }
+
+__device__ __forceinline__ uintptr_t sel_addr_s(bool ok, uintptr_t a, uintptr_t z) {
+    return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
+}
+
+// ELU on a bf16 fragment; expm1 by its series near 0 (exp(v) - 1 cancels there), __expf elsewhere: both well inside
+// half a bf16 ulp of expm1f
+__device__ __forceinline__ bf16x8 elu_frag(bf16x8 v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float f = (float)v[i];
+        const float series = f * (1.f + f * (0.5f + f * (1.f / 6.f)));
+        const float e = f > -0.03f ? series : __expf(f) - 1.f;
+        o[i] = (__bf16)(f > 0.f ? f : e);
+    }
+    return o;
+}
+
+// n -> (n / L, n % L) for 0 <= n < 2^30 and quotients far below 2^20: float estimate, one correction each way
+__device__ __forceinline__ void divmod_small(int n, int L, float rcpL, int& q, int& rem) {
+    q = (int)((float)n * rcpL);
+    rem = n - q * L;
+    if (rem < 0) { rem += L; --q; }
+    if (rem >= L) { rem -= L; ++q; }
+}
+
+template <int MT, int KS, int NT, bool PRE_ELU, int SIDE>
+__global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot, int ng, float rcpL) {
+    constexpr int WMR = MT * 32;
+    constexpr int EPF = WMR + 4;
+    constexpr int LPR = WMR / 8;    // lanes per staged row (8 output channels each)
+    constexpr int RPP = 64 / LPR;   // rows per pass
+    constexpr int NPS = 32 / RPP;   // passes per 32-row tile
+    __shared__ __attribute__((aligned(16))) float stage_all[4 * 32 * EPF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int Cin = p.Cin, Ktot = p.J * Cin, S = p.in_stride, Lout = p.Lout;
+    const int off0 = p.off0 + p.phase_off0[0];
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+    const bf16_t* __restrict__ w = (const bf16_t*)p.w;
+
+    // weights: A fragment (mt, ks) of lane (r, h) = w[mt*32 + r][ks*16 + h*8 .. +8]
+    bf16x8 a[MT][KS];
+    int dR[KS], cc[KS];
+    bool kin[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = ks * 16 + h * 8;
+        kin[ks] = k < Ktot;
+        const int j = k / Cin;
+        dR[ks] = j * p.tap_step;
+        cc[ks] = k - j * Cin;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 32 + r;
+            const bool ok = kin[ks] && m < p.M;
+            a[mt][ks] = ldg_frag(sel_addr_s(ok, (uintptr_t)(w + (size_t)m * Ktot + k), zero));
+        }
+    }
+
+    float* const stage = stage_all + wid * (32 * EPF);
+    bf16_t* __restrict__ y = (bf16_t*)p.y;
+    const bf16_t* __restrict__ side_src = SIDE == SIDE_RES ? (const bf16_t*)p.res : (const bf16_t*)p.dact_src;
+    const int erow = lane / LPR, m0 = (lane % LPR) * 8;
+    const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
+    const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
+    const bool delu = p.dact_mode == GA_DACT_ELU_FROM_IN;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && m0 < p.M) {
+        const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+
+    // x fragments of group g (every load is issued; rows or k past the end read the zero page)
+    auto load = [&](bf16x8 (&buf)[NT][KS], int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (g * NT + nt) * 32 + r;
+            int b, tl;
+            divmod_small(n, Lout, rcpL, b, tl);
+            const bool valid = n < Ntot;
+            const bf16_t* base = (const bf16_t*)p.x + (size_t)b * p.Lin * Cin;
+            const int R0 = (p.t0 + tl) * S + off0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int R = R0 + dR[ks];
+                if (R < 0 && p.pad_mode == 1) R = -R;
+                const bool ok = valid && kin[ks] && R >= 0 && R < p.Lin;
+                buf[nt][ks] = ldg_frag(sel_addr_s(ok, (uintptr_t)(base + (size_t)R * Cin + cc[ks]), zero));
+            }
+        }
+    };
+
+    // output element offset of this lane's 8 channels in pass ps of tile nt of group g (-1: nothing to write)
+    auto out_offset = [&](int g, int nt, int ps) __attribute__((always_inline)) -> long {
+        const int n = (g * NT + nt) * 32 + ps * RPP + erow;
+        int b, tl;
+        divmod_small(n, Lout, rcpL, b, tl);
+        const int orow = (p.t0 + tl) * p.out_stride;
+        const size_t in_item = (size_t)orow * p.M + m0;
+        const bool ok = n < Ntot && m0 < p.M && orow >= 0 && orow < p.LoutTot && in_item + 8 <= item_elems;
+        return ok ? (long)((size_t)b * item_elems + in_item) : -1L;
+    };
+
+    auto compute = [&](bf16x8 (&buf)[NT][KS], bf16x8 (&side)[NT][NPS], int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xb = PRE_ELU ? elu_frag(buf[nt][ks]) : buf[nt][ks];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], xb, acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(stage + r * EPF + mt * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = ps * RPP + erow;
+                const long o = out_offset(g, nt, ps);
+                float v[8];
+                *(float4*)&v[0] = *(const float4*)(stage + row * EPF + m0);
+                *(float4*)&v[4] = *(const float4*)(stage + row * EPF + m0 + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] += bv[i];
+                    v[i] = v[i] > 0.f ? v[i] : slope * v[i];
+                }
+                if (SIDE == SIDE_DACT) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float sv = (float)side[nt][ps][i];
+                        v[i] *= sv > 0.f ? 1.f : (delu ? __expf(sv) : 0.2f);
+                    }
+                }
+                if (SIDE == SIDE_RES) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += (float)side[nt][ps][i];
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                if (o >= 0) *(bf16x8*)(y + o) = ov;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    auto load_side = [&](bf16x8 (&side)[NT][NPS], int g) __attribute__((always_inline)) {
+        if (SIDE == SIDE_NONE) return;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const long o = out_offset(g, nt, ps);
+                side[nt][ps] = ldg_frag(sel_addr_s(o >= 0, (uintptr_t)(side_src + (o >= 0 ? o : 0)), zero));
+            }
+    };
+
+    const int stride = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wid;
+    if (g >= ng) return;
+    bf16x8 b0[NT][KS], b1[NT][KS], sd[NT][NPS];
+    load(b0, g);
+    while (true) {  // two groups per trip: the buffers swap roles by name, never by copy
+        load_side(sd, g);
+        load(b1, min(g + stride, ng - 1));
+        compute(b0, sd, g);
+        g += stride;
+        if (g >= ng) break;
+        load_side(sd, g);
+        load(b0, min(g + stride, ng - 1));
+        compute(b1, sd, g);
+        g += stride;
+        if (g >= ng) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int stream_side(const ConvParams& p) {
+    if (p.res && (p.dact_mode || p.dact_src)) return -1;
+    if (p.res) return SIDE_RES;
+    if (p.dact_mode) return SIDE_DACT;
+    return SIDE_NONE;
+}
+
+int ga_conv_stream_supported(const ConvParams& p) {
+    if (p.pre_act != GA_ACT_NONE && p.pre_act != GA_ACT_ELU) return 0;
+    if (p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
+    if (p.dact_mode != GA_DACT_NONE && p.dact_mode != GA_DACT_ELU_FROM_IN && p.dact_mode != GA_DACT_LRELU_FROM_OUT) return 0;
+    if (p.dact_mode && !p.dact_src) return 0;
+    if (p.accumulate || p.out_f32 || stream_side(p) < 0) return 0;
+    if (p.pre_act == GA_ACT_ELU && p.dact_mode) return 0;  // (not instantiated: a forward fuses ELU, a data gradient its derivative)
+    if (p.nphase != 1 || p.ksplit > 1) return 0;
+    if (p.Cin % 8 || p.Cin < 8 || p.M % 8 || p.M < 8 || p.M > 64 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if ((long)p.J * p.Cin > STREAM_KMAX) return 0;
+    if (p.y_batch_elems < 0 || (p.y_batch_elems > 0 && (p.y_batch_elems % 8 || (long)p.y_batch_elems > (long)p.LoutTot * p.M))) return 0;
+    if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
+    if ((long)p.B * p.Lout > (1L << 30) || p.B > (1 << 18)) return 0;
+    return 1;
+}
+
+template <int MT, int KS, int NT>
+static int launch_stream(const ConvParams& p, hipStream_t s) {
+    const int Ntot = p.B * p.Lout;
+    const int ng = (Ntot + 32 * NT - 1) / (32 * NT);
+    if (ng <= 0) return GA_OK;
+    int grid = (ng + 3) / 4;
+    if (grid > 2048) grid = 2048;  // 8 workgroups per CU; the waves stride over the rest
+    const float rcpL = 1.0f / (float)p.Lout;
+    const int side = stream_side(p);
+    if (p.pre_act == GA_ACT_ELU) {
+        if (side == SIDE_RES) conv_stream_kernel<MT, KS, NT, true, SIDE_RES><<<grid, 256, 0, s>>>(p, Ntot, ng, rcpL);
+        else conv_stream_kernel<MT, KS, NT, true, SIDE_NONE><<<grid, 256, 0, s>>>(p, Ntot, ng, rcpL);
+    } else {
+        if (side == SIDE_RES) conv_stream_kernel<MT, KS, NT, false, SIDE_RES><<<grid, 256, 0, s>>>(p, Ntot, ng, rcpL);
+        else if (side == SIDE_DACT) conv_stream_kernel<MT, KS, NT, false, SIDE_DACT><<<grid, 256, 0, s>>>(p, Ntot, ng, rcpL);
+        else conv_stream_kernel<MT, KS, NT, false, SIDE_NONE><<<grid, 256, 0, s>>>(p, Ntot, ng, rcpL);
+    }
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+template <int MT>
+static int launch_stream_mt(const ConvParams& p, hipStream_t s) {
+    const int ks = (p.J * p.Cin + 15) / 16;
+    if (ks <= 1) return launch_stream<MT, 1, 4>(p, s);
+    if (ks <= 2) return launch_stream<MT, 2, MT == 1 ? 4 : 2>(p, s);
+    if (ks <= 4) return launch_stream<MT, 4, 2>(p, s);
+    if (ks <= 6) return launch_stream<MT, 6, 1>(p, s);
+    if (ks <= 8) return launch_stream<MT, 8, 1>(p, s);
+    return launch_stream<MT, 12, 1>(p, s);
+}
+
+int ga_conv_stream_impl(const ConvParams& p, hipStream_t s) {
+    if (!ga_conv_stream_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
+    if (p.Lout == 0) return GA_OK;
+    return p.M <= 32 ? launch_stream_mt<1>(p, s) : launch_stream_mt<2>(p, s);
+}

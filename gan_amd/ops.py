@@ -457,6 +457,17 @@ def act_fwd(x: Tensor, act: int) -> Tensor:
     return y
 
 
+def _streams_with_pre_act(g: ConvGeom, x: Tensor, pre_act: int) -> bool:
+    """True when ga_conv would run this forward, input activation included, on the register-streaming MFMA kernel."""
+    if _IMPL not in (L.IMPL_AUTO, L.IMPL_MFMA):
+        return False
+    p = fwd_params(g, x.shape[0], x.shape[1])
+    p.pre_act = pre_act
+    if MERGE_PHASES:
+        p, _ = _fold_phases(p, x, None)
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) == L.KERNEL_STREAM
+
+
 class ConvFrozen(torch.autograd.Function):
     """y = conv(pre_act(x)) + bias (+ res) with frozen weights (SEANet decoder): only dx is produced.
     dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
@@ -464,9 +475,9 @@ class ConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False):
         x = x.contiguous()
-        if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16:
+        if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and not _streams_with_pre_act(geom, x, pre_act):
             # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
-            # which cannot transform its operand in flight
+            # which cannot transform its operand in flight (the thin layers' streaming kernel can: no copy there)
             y = conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, res=None if res is None else res.contiguous(), out_f32=out_f32)
         else:
             y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)

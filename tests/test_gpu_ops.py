@@ -172,6 +172,61 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     close(outs[L.IMPL_MFMA][1], outs[L.IMPL_DIRECT][1], 1e-2, f"{g} dgrad")
 
 
+STREAM_CASES = [
+    # thin layers (M <= 64, K = J*Cin <= 192): operands straight from global memory into MFMA fragments
+    (ConvGeom("cconv", 64, 32, 3), 1201, 3),       # K = 192: 12 k-steps, no register double buffer
+    (ConvGeom("cconv", 32, 16, 3), 901, 2),        # K = 96, 16 output channels (half an MFMA tile)
+    (ConvGeom("cconv", 16, 32, 1), 901, 2),        # K = 16: one k-step, four row groups per trip
+    (ConvGeom("cconv", 32, 64, 1), 777, 2),        # two m tiles
+    (ConvGeom("cconv", 64, 64, 1), 515, 3),
+    (ConvGeom("convt", 64, 32, 4, 2), 400, 3),     # folded phases: rows of 64 channels, per-item element bound
+    (ConvGeom("conv", 16, 48, 5, 2, 2, 1), 301, 2),  # K = 80 (bucket of 6 k-steps), M = 48, strided
+    (ConvGeom("conv", 24, 40, 3, 1, 1, 1), 130, 5),  # Cin = 24: taps change inside a k-step pair; tiles span batch items
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0].kind}-{c[0].cin}-{c[0].cout}-k{c[0].k}s{c[0].stride}-L{c[1]}")
+def test_stream_kernel_matches_direct(case):
+    """conv_stream_kernel must be what AUTO picks for the thin bf16 layers, with and without the fused input ELU, and
+    must agree with the direct fp32-FMA kernel on the same operands: forward (ELU in, bias, residual) and data
+    gradient (ELU derivative from the saved input)."""
+    import ctypes
+    g, Ln, B = case
+    torch.manual_seed(14)
+    x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+    d0, d1, k = g.wdims
+    w = torch.randn(d0, d1, k, device=DEV) / (g.cin * g.k) ** 0.5
+    bias = torch.randn(g.cout, device=DEV)
+    Lo = g.out_len(Ln)
+    gy = torch.randn(B, Lo, g.cout, device=DEV).bfloat16()
+    res = torch.randn(B, Lo, g.cout, device=DEV).bfloat16()
+    p = ops.fwd_params(g, B, Ln)
+    if g.kind != "convt":
+        assert L.lib().ga_conv_kernel_id(ctypes.byref(p), 1, L.IMPL_AUTO) == L.KERNEL_STREAM
+        p.pre_act = L.ACT_ELU
+        assert L.lib().ga_conv_kernel_id(ctypes.byref(p), 1, L.IMPL_AUTO) == L.KERNEL_STREAM
+    wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+    outs = {}
+    for impl in (L.IMPL_AUTO, L.IMPL_DIRECT):
+        ops.set_conv_impl(impl)
+        try:
+            ops.PROFILE = []
+            y0 = ops.conv_forward(g, x, wf, bias)
+            y1 = ops.conv_forward(g, x, wf, bias, pre_act=L.ACT_ELU, res=res)
+            dx0 = ops.conv_dgrad(g, gy, wd, Ln)
+            dx1 = ops.conv_dgrad(g, gy, wd, Ln, dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
+            kids = [e[0] for e in ops.PROFILE]
+            outs[impl] = [t.float().cpu() for t in (y0, y1, dx0, dx1)]
+        finally:
+            ops.PROFILE = None
+            ops.set_conv_impl(L.IMPL_AUTO)
+        if impl == L.IMPL_AUTO:
+            # (the causal convs' reflected-pad fix-up launches accumulate into dx: those stay with the gathered GEMM)
+            assert sum(kk == L.KERNEL_STREAM for kk in kids) == 4 and all(kk in L.GEMM_KERNELS for kk in kids), kids
+    for i, name in enumerate(("fwd", "fwd elu+res", "dgrad", "dgrad*elu'")):
+        close(outs[L.IMPL_AUTO][i], outs[L.IMPL_DIRECT][i], 1e-2, f"{g} {name}")
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
