@@ -35,18 +35,32 @@ __device__ __forceinline__ uintptr_t sel_addr_s(bool ok, uintptr_t a, uintptr_t 
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
 }
 
-// ELU on a bf16 fragment; expm1 by its series near 0 (exp(v) - 1 cancels there), __expf elsewhere: both well inside
-// half a bf16 ulp of expm1f
+// ELU on a bf16 fragment, two elements per step so that the multiply / add / convert are packed instructions.
+// f > -2^-12 returns f itself (for -2^-12 < f < 0, expm1(f) = f to well inside half a bf16 ulp, and exp(f) - 1 would
+// cancel there), so one compare serves both the positive side and the cancellation guard.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 elu_frag(bf16x8 v) {
-    bf16x8 o;
+    union { bf16x8 b; unsigned int u[4]; } in, out;
+    in.b = v;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float f = (float)v[i];
-        const float series = f * (1.f + f * (0.5f + f * (1.f / 6.f)));
-        const float e = f > -0.03f ? series : __expf(f) - 1.f;
-        o[i] = (__bf16)(f > 0.f ? f : e);
+    for (int i = 0; i < 4; ++i) {
+        f32x2 f;
+        f.x = __uint_as_float(in.u[i] << 16);
+        f.y = __uint_as_float(in.u[i] & 0xffff0000u);
+        const f32x2 t = f * 1.4426950408889634f;
+        f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(t.x);
+        e.y = __builtin_amdgcn_exp2f(t.y);
+        e = e - 1.0f;
+        const float rx = f.x > -2.44140625e-4f ? f.x : e.x;
+        const float ry = f.y > -2.44140625e-4f ? f.y : e.y;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        union { bf16x2 b; unsigned int u; } pk;
+        pk.b[0] = (__bf16)rx;
+        pk.b[1] = (__bf16)ry;
+        out.u[i] = pk.u;
     }
-    return o;
+    return out.b;
 }
 
 // n -> (n / L, n % L) for 0 <= n < 2^30 and quotients far below 2^20: float estimate, one correction each way
