@@ -74,6 +74,101 @@ __global__ void unpack_grad_kernel(const float* __restrict__ packed, float* __re
     }
 }
 
+// LDS-tiled forms of the two kernels above: the packed layouts transpose the tap axis against a channel axis, so a
+// one-element-per-thread copy is coalesced on one side only (2- or 4-byte accesses at a stride on the other).  A tile is
+// read in the source's order, parked in LDS, and written in the destination's order.
+//   FAST0 (destination runs along s0: the data-gradient packs, transposed-conv forward): 64 s0 x 64 consecutive (s1,k)
+//   else  (destination runs along s1: forward pack, transposed-conv data gradient):       one s0 x 64 s1 x all K (K <= 65)
+// UNPACK = true moves packed fp32 gradients back to the parameter layout (the same tiles, roles of the sides swapped).
+template <typename T, bool FAST0, bool UNPACK>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                          T* __restrict__ dst, float* __restrict__ dw,
+                                                          const float* __restrict__ packed, int mode, int D0, int D1, int K,
+                                                          int S, int P, int accumulate) {
+    __shared__ float tile[64 * 65];
+    const int tid = threadIdx.x;
+    const size_t DK = (size_t)D1 * K;
+    if (FAST0) {
+        const int s0b = blockIdx.x * 64;
+        const size_t eb = (size_t)blockIdx.y * 64;
+        if (!UNPACK) {
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int sl = idx >> 6, el = idx & 63;
+                const int s0 = s0b + sl;
+                const size_t e = eb + el;
+                if (s0 < D0 && e < DK) tile[sl * 65 + el] = src[(size_t)s0 * DK + e] * (scale ? scale[s0] : 1.f);
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int el = idx >> 6, sl = idx & 63;
+                const int s0 = s0b + sl;
+                const size_t e = eb + el;
+                if (s0 < D0 && e < DK) dst[pack_index(mode, s0, (int)(e / K), (int)(e % K), D0, D1, K, S, P)] = (T)tile[sl * 65 + el];
+            }
+        } else {
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int el = idx >> 6, sl = idx & 63;
+                const int s0 = s0b + sl;
+                const size_t e = eb + el;
+                if (s0 < D0 && e < DK) tile[sl * 65 + el] = packed[pack_index(mode, s0, (int)(e / K), (int)(e % K), D0, D1, K, S, P)];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int sl = idx >> 6, el = idx & 63;
+                const int s0 = s0b + sl;
+                const size_t e = eb + el;
+                if (s0 < D0 && e < DK) {
+                    const size_t i = (size_t)s0 * DK + e;
+                    dw[i] = accumulate ? dw[i] + tile[sl * 65 + el] : tile[sl * 65 + el];
+                }
+            }
+        }
+    } else {
+        const int s0 = blockIdx.x;
+        const int s1b = blockIdx.y * 64;
+        const int ns1 = min(64, D1 - s1b);
+        const int ne = ns1 * K;
+        const size_t base = ((size_t)s0 * D1 + s1b) * K;
+        const float sc = (!UNPACK && scale) ? scale[s0] : 1.f;
+        if (!UNPACK) {
+            for (int idx = tid; idx < ne; idx += 256) tile[idx] = src[base + idx] * sc;
+            __syncthreads();
+            for (int idx = tid; idx < 64 * K; idx += 256) {
+                const int k = idx >> 6, s1l = idx & 63;
+                if (s1l < ns1) dst[pack_index(mode, s0, s1b + s1l, k, D0, D1, K, S, P)] = (T)tile[s1l * K + k];
+            }
+        } else {
+            for (int idx = tid; idx < 64 * K; idx += 256) {
+                const int k = idx >> 6, s1l = idx & 63;
+                if (s1l < ns1) tile[s1l * K + k] = packed[pack_index(mode, s0, s1b + s1l, k, D0, D1, K, S, P)];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < ne; idx += 256) dw[base + idx] = accumulate ? dw[base + idx] + tile[idx] : tile[idx];
+        }
+    }
+}
+
+static inline bool pack_fast0(int mode) {
+    return mode == GA_PACK_CONV_DGRAD_S1 || mode == GA_PACK_CONV_DGRAD_STRIDED || mode == GA_PACK_CONVT_FWD;
+}
+
+// launches the tiled pack / unpack; false when the shape does not fit the tiles (callers fall back to the plain kernels)
+template <typename T, bool UNPACK>
+static bool launch_pack_tiled(const float* src, const float* scale, T* dst, float* dw, const float* packed, int mode, int D0,
+                              int D1, int K, int S, int P, int accumulate, hipStream_t s) {
+    const size_t DK = (size_t)D1 * K;
+    if (D0 * DK < 16384) return false;  // small weights: one plain launch is as good
+    if (pack_fast0(mode)) {
+        const size_t gy = (DK + 63) / 64;
+        if (gy > 65535) return false;
+        pack_tiled_kernel<T, true, UNPACK><<<dim3((D0 + 63) / 64, (unsigned)gy), 256, 0, s>>>(src, scale, dst, dw, packed, mode, D0, D1, K, S, P, accumulate);
+    } else {
+        if (K > 65 || (D1 + 63) / 64 > 65535) return false;
+        pack_tiled_kernel<T, false, UNPACK><<<dim3(D0, (D1 + 63) / 64), 256, 0, s>>>(src, scale, dst, dw, packed, mode, D0, D1, K, S, P, accumulate);
+    }
+    return true;
+}
+
 // weight-norm backward on the effective-weight gradient dw[R][n]:
 //   dg[r] = <dw_r, v_r> / ||v_r||;  dv_r = (g/||v||) * dw_r - (g * <dw_r, v_r> / ||v||^3) * v_r
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
@@ -720,15 +815,21 @@ int ga_pack_weights(const float* src, const float* scale, void* dst, int dtype, 
     if (mode == GA_PACK_CONV_DGRAD_STRIDED) {
         if (hipMemsetAsync(dst, 0, ga_packed_elems(mode, D0, D1, K, S) * esz, s) != hipSuccess) return GA_ERR_LAUNCH;
     }
-    DISPATCH_T(dtype, (pack_weights_kernel<float><<<grid_for(n), 256, 0, s>>>(src, scale, (float*)dst, mode, D0, D1, K, S, P)),
-               (pack_weights_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>(src, scale, (bf16_t*)dst, mode, D0, D1, K, S, P)));
+    const bool tiled = dtype == GA_DTYPE_BF16
+        ? launch_pack_tiled<bf16_t, false>(src, scale, (bf16_t*)dst, nullptr, nullptr, mode, D0, D1, K, S, P, 0, s)
+        : launch_pack_tiled<float, false>(src, scale, (float*)dst, nullptr, nullptr, mode, D0, D1, K, S, P, 0, s);
+    if (!tiled) {
+        DISPATCH_T(dtype, (pack_weights_kernel<float><<<grid_for(n), 256, 0, s>>>(src, scale, (float*)dst, mode, D0, D1, K, S, P)),
+                   (pack_weights_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>(src, scale, (bf16_t*)dst, mode, D0, D1, K, S, P)));
+    }
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
 
 int ga_unpack_grad(const float* packed, float* dw, int mode, int D0, int D1, int K, int S, int P, int accumulate, hipStream_t s) {
     if (!packed || !dw || D0 <= 0 || D1 <= 0 || K <= 0 || mode < 0 || mode > 4) return GA_ERR_ARG;
-    unpack_grad_kernel<<<grid_for((size_t)D0 * D1 * K), 256, 0, s>>>(packed, dw, mode, D0, D1, K, S, P, accumulate);
+    if (!launch_pack_tiled<float, true>(nullptr, nullptr, (float*)nullptr, dw, packed, mode, D0, D1, K, S, P, accumulate, s))
+        unpack_grad_kernel<<<grid_for((size_t)D0 * D1 * K), 256, 0, s>>>(packed, dw, mode, D0, D1, K, S, P, accumulate);
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

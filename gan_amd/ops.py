@@ -251,7 +251,7 @@ def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
     B, lout, cout = ga.shape
     p = L.WgradParams()
     ndw = g.cout * g.k * g.cin
-    buf = torch.zeros((ndw + (g.cout if want_bias else 0),), device=x.device, dtype=torch.float32)  # one fill for both
+    buf = zeros_f32(ndw + (g.cout if want_bias else 0), x.device)  # one buffer for both
     dw = buf[:ndw].view(g.cout, g.k, g.cin)
     db = buf[ndw:] if want_bias else None
     _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=L.ptr(db), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout,
@@ -324,6 +324,30 @@ def _zero_scalar(device) -> Tensor:
     if z is None:
         z = _ZERO1[device] = torch.zeros((1,), device=device, dtype=torch.float32)
     return z
+
+
+# ---- pre-zeroed fp32 arena -----------------------------------------------------------------------
+# Every atomically accumulated result (weight / bias / affine gradients, loss sums) needs a zeroed fp32 buffer; a training
+# step asks for ~180 of them, most a few KB.  They are carved from chunks zeroed by ONE fill each instead of one tiny fill
+# launch per buffer.  A carved slice is handed out once and never reused; a chunk lives as long as any slice of it does.
+ZERO_ARENA = True
+_ARENA_CHUNK = 4 << 20        # floats per chunk (16 MiB: one ~6 us fill)
+_ARENA_MAX_CARVE = 1 << 20    # larger requests get their own torch.zeros (the fill is bandwidth, not launch, there)
+_ARENA: dict = {}             # device -> [chunk, offset]
+
+
+def zeros_f32(n: int, device) -> Tensor:
+    if not ZERO_ARENA or n > _ARENA_MAX_CARVE:
+        return torch.zeros((n,), device=device, dtype=torch.float32)
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ent = _ARENA.get(key)
+    n_al = (n + 63) // 64 * 64  # 256-byte granules
+    if ent is None or ent[1] + n_al > ent[0].numel():
+        ent = _ARENA[key] = [torch.zeros((_ARENA_CHUNK,), device=device, dtype=torch.float32), 0]
+    out = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n_al
+    return out
 
 
 class PackTrainable(torch.autograd.Function):
@@ -400,7 +424,7 @@ def act_bwd(gy: Tensor, src: Tensor, mode: int) -> Tensor:
 
 def colsum(g: Tensor) -> Tensor:
     M = g.shape[-1]
-    out = torch.zeros((M,), device=g.device, dtype=torch.float32)
+    out = zeros_f32(M, g.device)
     L.check(L.lib().ga_colsum(g.data_ptr(), L.dt(g), g.numel() // M, M, out.data_ptr(), L.stream()), "ga_colsum")
     return out
 
@@ -432,7 +456,7 @@ class ConvTrain(torch.autograd.Function):
         if ctx.post_act == L.ACT_LRELU and want_b and M % ev == 0 and 256 % (M // ev) == 0:
             # mask and bias gradient in one pass over gy
             ga = torch.empty_like(gy)
-            gb = torch.zeros((M,), device=gy.device, dtype=torch.float32)
+            gb = zeros_f32(M, gy.device)
             L.check(L.lib().ga_act_bwd_bias(gy.data_ptr(), y.data_ptr(), ga.data_ptr(), L.dt(gy), gy.numel() // M, M,
                                             L.DACT_LRELU_FROM_OUT, gb.data_ptr(), L.stream()), "ga_act_bwd_bias")
             want_b = False
@@ -535,7 +559,7 @@ class GnFilmAct(torch.autograd.Function):
         B, T, Cn = x.shape
         dx = torch.empty_like(x)
         nab = ab.numel() if ab is not None else 0
-        zbuf = torch.zeros((2 * gamma.numel() + nab,), device=gamma.device, dtype=torch.float32)  # one fill for all three
+        zbuf = zeros_f32(2 * gamma.numel() + nab, gamma.device)  # one buffer for all three
         dgamma = zbuf[:gamma.numel()].view_as(gamma)
         dbeta = zbuf[gamma.numel():2 * gamma.numel()].view_as(beta)
         dab = zbuf[2 * gamma.numel():].view_as(ab) if ab is not None else None
@@ -613,7 +637,7 @@ class ReduceSum(torch.autograd.Function):
             if perm_b != perm:
                 bf = (b.permute(0, 2, 1) if perm else b).contiguous()
             assert bf.shape == af.shape and bf.dtype == af.dtype, "operands must share shape and dtype"
-        out = torch.zeros((1,), device=a.device, dtype=torch.float32)
+        out = zeros_f32(1, a.device)
         L.check(L.lib().ga_reduce(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), op, 1.0, out.data_ptr(), L.stream()), "ga_reduce")
         ctx.save_for_backward(af, bf)
         ctx.op = op
@@ -650,7 +674,7 @@ class LatentSums(torch.autograd.Function):
         qs = qs.contiguous()
         assert qh.shape == qs.shape and qh.dtype == qs.dtype
         B, T, Cn = qh.shape
-        out = torch.zeros((2 + B,), device=qh.device, dtype=torch.float32)
+        out = zeros_f32(2 + B, qh.device)
         L.check(L.lib().ga_latent_loss_fwd(qh.data_ptr(), qs.data_ptr(), L.dt(qh), B, T, Cn, out.data_ptr(), L.stream()),
                 "ga_latent_loss_fwd")
         ctx.save_for_backward(qh, qs)
@@ -735,7 +759,7 @@ class StftSums(torch.autograd.Function):
             spec = torch.empty((B, frames, M), device=x.device, dtype=torch.float32)
             _launch_conv(p, xp, w_f, spec, impl=_IMPL)
             specs.append(spec)
-        out = torch.zeros((3,), device=x.device, dtype=torch.float32)
+        out = zeros_f32(3, x.device)
         L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.DT_F32, B * frames, nb, M, out.data_ptr(),
                                      L.stream()), "ga_stft_loss_fwd")
         ctx.save_for_backward(specs[0], specs[1], w_d)
@@ -787,7 +811,7 @@ class LstmSkip(torch.autograd.Function):
         y = torch.empty_like(x)
         h1 = torch.empty((B, T, H), device=dev, dtype=dtype)
         h2 = torch.empty((B, T, H), device=dev, dtype=dtype)
-        c = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
+        c = zeros_f32(2 * B * H, dev).view(2, B, H)
         gates = torch.empty((2, Bg, T, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
         cs = torch.empty((2, Bg, T, H), device=dev, dtype=torch.float32) if need_grad else None
         p = L.LstmParams()
@@ -813,7 +837,7 @@ class LstmSkip(torch.autograd.Function):
         dy = dy[:B].contiguous()
         dev, dtype = dy.device, dy.dtype
         dg = torch.empty((2, B, T, 4 * H), device=dev, dtype=dtype)
-        dc = torch.zeros((2, B, H), device=dev, dtype=torch.float32)
+        dc = zeros_f32(2 * B * H, dev).view(2, B, H)
         p = L.LstmBwdParams()
         _fill(p, w1t=w["hh0_t"].data_ptr(), w2t=w["cat1_t"].data_ptr(), dy=dy.data_ptr(), gates1=gates[0].data_ptr(),
               gates2=gates[1].data_ptr(), cs1=cs[0].data_ptr(), cs2=cs[1].data_ptr(), dg1=dg[0].data_ptr(), dg2=dg[1].data_ptr(),

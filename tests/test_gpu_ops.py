@@ -227,6 +227,55 @@ def test_stream_kernel_matches_direct(case):
         close(outs[L.IMPL_AUTO][i], outs[L.IMPL_DIRECT][i], 1e-2, f"{g} {name}")
 
 
+def _pack_index_ref(mode, D0, D1, K, S, P):
+    """Packed position of every source weight element (s0, s1, k): the documented layouts of ga_pack_weights."""
+    s0, s1, k = torch.meshgrid(torch.arange(D0), torch.arange(D1), torch.arange(K), indexing="ij")
+    if mode == L.PACK_CONV_FWD:
+        return (s0 * K + k) * D1 + s1
+    if mode == L.PACK_CONV_DGRAD_S1:
+        return (s1 * K + (K - 1 - k)) * D0 + s0
+    if mode == L.PACK_CONV_DGRAD_STRIDED:
+        jmax = (K + S - 1) // S
+        r = (k % S - P) % S
+        return ((r * D1 + s1) * jmax + (jmax - 1 - k // S)) * D0 + s0
+    if mode == L.PACK_CONVT_FWD:
+        return (((k % S) * D1 + s1) * 2 + (1 - k // S)) * D0 + s0
+    return (s0 * K + k) * D1 + s1
+
+
+@pytest.mark.parametrize("shape", [(256, 128, 41, 4, 20), (130, 70, 11, 1, 5), (64, 32, 15, 1, 7), (512, 256, 16, 8, 0), (96, 200, 3, 1, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_tiled_pack_and_unpack_match_layout_definition(shape):
+    """ga_pack_weights / ga_unpack_grad (LDS-tiled transposes for the larger weights) against the layout definition,
+    every mode, ragged tiles, with and without the weight-norm row scale; unpack(pack(w)) == w."""
+    D0, D1, K, S, P = shape
+    torch.manual_seed(5)
+    w = torch.randn(D0, D1, K, device=DEV)
+    scale = torch.rand(D0, device=DEV) + 0.5
+    lib = L.lib()
+    for mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD_S1, L.PACK_CONV_DGRAD_STRIDED, L.PACK_CONVT_FWD, L.PACK_CONVT_DGRAD):
+        if mode == L.PACK_CONVT_FWD and K != 2 * S:
+            continue
+        if mode == L.PACK_CONV_DGRAD_STRIDED and S == 1:
+            continue
+        n = lib.ga_packed_elems(mode, D0, D1, K, S)
+        idx = _pack_index_ref(mode, D0, D1, K, S, P).reshape(-1)
+        for sc in (None, scale):
+            for dtype in (torch.float32, torch.bfloat16):
+                out = torch.full((n,), 7.0, device=DEV, dtype=dtype)
+                L.check(lib.ga_pack_weights(w.data_ptr(), L.ptr(sc), out.data_ptr(), L.dt(out), mode, D0, D1, K, S, P, L.stream()), "pack")
+                src = w if sc is None else w * sc[:, None, None]
+                want = torch.zeros(n, dtype=dtype) if mode == L.PACK_CONV_DGRAD_STRIDED else torch.full((n,), 7.0, dtype=dtype)
+                want[idx] = src.cpu().to(dtype).reshape(-1)
+                assert torch.equal(out.cpu(), want), (mode, sc is not None, dtype)
+        packed = torch.randn(n, device=DEV)
+        for acc in (0, 1):
+            dw = torch.ones(D0, D1, K, device=DEV)
+            L.check(lib.ga_unpack_grad(packed.data_ptr(), dw.data_ptr(), mode, D0, D1, K, S, P, acc, L.stream()), "unpack")
+            want = packed.cpu()[idx].reshape(D0, D1, K) + (1.0 if acc else 0.0)
+            assert torch.equal(dw.cpu(), want), (mode, acc)
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
