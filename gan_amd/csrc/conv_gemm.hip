@@ -34,6 +34,15 @@ __device__ __forceinline__ uintptr_t sel_addr(bool ok, uintptr_t a, uintptr_t z)
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
 }
 
+// n -> (n / d, n % d) for 0 <= n < 2^30 and quotients far below 2^20: reciprocal estimate, one correction each way.
+// (An integer division is ~40 dependent instructions; with one wave per SIMD -- small grids -- they are not hidden.)
+__device__ __forceinline__ void divmod_small(int n, int d, float rcp, int& q, int& rem) {
+    q = (int)((float)n * rcp);
+    rem = n - q * d;
+    if (rem < 0) { rem += d; --q; }
+    if (rem >= d) { rem -= d; ++q; }
+}
+
 // MI: 32-row MFMA tiles per wave along m (2: wave tile 64 x 64, 1: wave tile 32 x 64 for layers with <= 32 output channels)
 template <int MI, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot) {
@@ -53,13 +62,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     if (wk >= total) return;
     // split-K: consecutive work items are the K slices of one output tile
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int split = wk % ksplit;
-    wk /= ksplit;
-    const int ks_begin = (int)((long)nsteps * split / ksplit), ks_end = (int)((long)nsteps * (split + 1) / ksplit);
-    const int my = wk / (nN * p.nphase);
-    const int rem = wk - my * (nN * p.nphase);
-    const int phase = rem / nN;
-    const int bx = rem - phase * nN;
+    int split = 0;
+    if (ksplit > 1) {
+        const int q = wk / ksplit;
+        split = wk - q * ksplit;
+        wk = q;
+    }
+    const int ks_begin = ksplit > 1 ? (int)((long)nsteps * split / ksplit) : 0;
+    const int ks_end = ksplit > 1 ? (int)((long)nsteps * (split + 1) / ksplit) : nsteps;
+    int my = 0, rem = wk, phase = 0, bx;
+    const int per_m = nN * p.nphase;
+    if (wk >= per_m) divmod_small(wk, per_m, __builtin_amdgcn_rcpf((float)per_m), my, rem);
+    bx = rem;
+    if (p.nphase > 1) divmod_small(rem, nN, __builtin_amdgcn_rcpf((float)nN), phase, bx);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -74,46 +89,86 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     // staging geometry: piece q = i*256 + tid -> row q>>3 = i*32 + (tid>>3), slot tid&7, logical piece below
     const int srow = tid >> 3;
     const int piece = (tid & 7) ^ ((tid >> 4) & 7);
-    const bf16_t* arow[NA];
+    // per-thread gather state.  The K position advances by 64 per stage, so tap j, channel c and the byte offset of
+    // (j, c) inside a row window are carried from stage to stage instead of being re-derived (no division, no multiply).
+    const float rcpL = __builtin_amdgcn_rcpf((float)p.Lout);
+    uintptr_t abase[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = mbase + i * 32 + srow;
-        arow[i] = (m < p.M && i * 32 + srow < BM) ? w + (size_t)m * Ktot : nullptr;
+        abase[i] = (m < p.M && i * 32 + srow < BM) ? (uintptr_t)(w + (size_t)m * Ktot) : 0;
     }
-    const bf16_t* brow[NB];
+    uintptr_t xitem[NB];  // start of the row's batch item (0: row past the end)
+    uintptr_t rb[NB];     // xitem + bR*Cin elements: address of (tap 0, channel 0) of the row's window, possibly out of range
     int bR[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int n = nbase + i * 32 + srow;
-        if (n < Ntot) {
-            const int b = n / p.Lout, t = p.t0 + (n - b * p.Lout);
-            brow[i] = (const bf16_t*)p.x + (size_t)b * p.Lin * Cin;
-            bR[i] = t * S + off0;
-        } else {
-            brow[i] = nullptr;
-            bR[i] = 0;
-        }
+        int b, tl;
+        divmod_small(n < Ntot ? n : 0, p.Lout, rcpL, b, tl);
+        xitem[i] = n < Ntot ? (uintptr_t)((const bf16_t*)p.x + (size_t)b * p.Lin * Cin) : 0;
+        bR[i] = (p.t0 + tl) * S + off0;
+        rb[i] = xitem[i] + (uintptr_t)((long)bR[i] * Cin * 2);
     }
+    const int tapB = p.tap_step * Cin * 2;  // bytes between taps in a row window
+    int st_dj, st_dc;
+    divmod_small(GBK, Cin, __builtin_amdgcn_rcpf((float)Cin), st_dj, st_dc);
+    const int st_ddR = st_dj * p.tap_step, st_dkk = st_dj * tapB + st_dc * 2;
+    int st_k = ks_begin * GBK + piece * 8, st_c, st_dR, st_kk;
+    {
+        int j0;
+        divmod_small(st_k, Cin, __builtin_amdgcn_rcpf((float)Cin), j0, st_c);
+        st_dR = j0 * p.tap_step;
+        st_kk = j0 * tapB + st_c * 2;
+    }
+    const bool reflect = p.pad_mode == 1;
 
-    auto issue = [&](int ks, int buf) {
-        const int k = ks * GBK + piece * 8;
-        const bool kin = k < Ktot;
-        const int j = k / Cin, c = k - j * Cin;
-        const int dR = j * p.tap_step;
+    // issues the direct-to-LDS loads of the NEXT stage in sequence (stages are issued in K order, each exactly once)
+    auto issue = [&](int buf) {
+        const bool kin = st_k < Ktot;
         char* const ab = Al + buf * (BM * 128) + wid * 1024;
         char* const bb = Bl + buf * (BN * 128) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            glds16(sel_addr(kin && arow[i], (uintptr_t)(arow[i] + k), zero), ab + i * 4096);
+            glds16(sel_addr(kin && abase[i], abase[i] + (uintptr_t)(st_k * 2), zero), ab + i * 4096);
         }
+        if (!reflect) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int R = bR[i] + dR;
-            if (R < 0 && p.pad_mode == 1) R = -R;
-            const bool ok = kin && brow[i] && R >= 0 && R < p.Lin;
-            glds16(sel_addr(ok, (uintptr_t)(brow[i] + (size_t)R * Cin + c), zero), bb + i * 4096);
+            for (int i = 0; i < NB; ++i) {
+                const int R = bR[i] + st_dR;
+                const bool ok = kin && xitem[i] && R >= 0 && R < p.Lin;
+                glds16(sel_addr(ok, rb[i] + (uintptr_t)(long)st_kk, zero), bb + i * 4096);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int R = bR[i] + st_dR;
+                if (R < 0) R = -R;
+                const bool ok = kin && xitem[i] && R < p.Lin;
+                glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * 4096);
+            }
+        }
+        st_k += GBK;
+        st_c += st_dc;
+        st_dR += st_ddR;
+        st_kk += st_dkk;
+        if (st_c >= Cin) {
+            st_c -= Cin;
+            st_dR += p.tap_step;
+            st_kk += tapB - Cin * 2;
         }
     };
+
+    // this lane's 8 bias values (the epilogue's channel group depends on the lane only): fetched here, behind the whole K loop,
+    // not once per epilogue pass in front of every store
+    constexpr int LPR_ = (MI * 32) / 8;
+    const int m0_ = mbase + wm * (MI * 32) + (lane % LPR_) * 8;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ksplit == 1 && m0_ < p.M) {
+        const float4 b0 = *(const float4*)(p.bias + m0_), b1 = *(const float4*)(p.bias + m0_ + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -126,16 +181,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const int swz = (r >> 1) & 7;
     const int aoff = (wm * WMR + r) * 128, boff = (wn * 64 + r) * 128;
 
-    if (NBUF == 2 && ks_begin < ks_end) issue(ks_begin, 0);
+    // NBUF >= 2: stages ks+1 .. ks+NBUF-1 are in flight while stage ks is multiplied (NBUF = 4 is for grids of about one
+    // workgroup per CU, where nothing else on the CU hides the load latency).  One barrier per K-step: behind it every
+    // wave's share of stage ks has landed and everyone is done reading the buffer that stage ks+NBUF-1 is about to refill.
+    constexpr int DEPTH = NBUF - 1;           // stages in flight ahead of the one being multiplied
+    constexpr int LPS = NA + NB;              // direct-to-LDS loads per thread per stage (the memory counter is in-order)
+    if (NBUF >= 2) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (ks_begin + d < ks_end) issue(d);
+    }
+    int buf = 0;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const int buf = NBUF == 2 ? ((ks - ks_begin) & 1) : 0;
         if (NBUF == 1) {
             if (ks > ks_begin) __syncthreads();  // everyone is done reading the single buffer
-            issue(ks, 0);
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int ahead = ks_end - 1 - ks;  // stages issued after stage ks
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // K-step ks has landed for every wave; everyone is done reading the other buffer
-        if (NBUF == 2 && ks + 1 < ks_end) issue(ks + 1, buf ^ 1);
+        if (NBUF > 2) {
+            // raw barrier: __syncthreads() would drain the memory counter (vmcnt(0)) and with it the stages in flight
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        if (NBUF >= 2 && ks + DEPTH < ks_end) {
+            int nb = buf + DEPTH;
+            if (nb >= NBUF) nb -= NBUF;
+            issue(nb);
+        }
         const char* Ab = Al + buf * (BM * 128) + aoff;
         const char* Bb = Bl + buf * (BN * 128) + boff;
 #pragma unroll
@@ -152,6 +234,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
+        if (NBUF >= 2 && ++buf == NBUF) buf = 0;
     }
 
     // ---- epilogue: accumulators -> wave-private LDS rows [n][m] -> 16-byte, row-contiguous global accesses ----
@@ -166,6 +249,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const int erow = lane / LPR, ec8 = (lane % LPR) * 8;
     const int m0 = mbase + wm * WMR + ec8;
     const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
+    const bool simple_act = p.post_act == GA_ACT_NONE || p.post_act == GA_ACT_LRELU;
+    const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -180,8 +265,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
             const int row = ps * RPP + erow;
             const int n = nbase + wn * 64 + ni * 32 + row;
             if (n >= Ntot || m0 >= p.M) continue;
-            const int b = n / p.Lout, t = p.t0 + (n - b * p.Lout);
-            const int orow = t * p.out_stride + phase;
+            int b, tl;
+            divmod_small(n, p.Lout, rcpL, b, tl);
+            const int orow = (p.t0 + tl) * p.out_stride + phase;
             if (orow < 0 || orow >= p.LoutTot) continue;
             const size_t in_item = (size_t)orow * p.M + m0;
             if (in_item + 8 > item_elems) continue;  // (folded phases: the last row may run past the item)
@@ -195,13 +281,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
                 *(float4*)(wo + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 continue;
             }
-            if (p.bias) {
-                const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
+            if (simple_act) {  // none / LeakyReLU: one multiply-select per element
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i]);
+                for (int i = 0; i < 8; ++i) {
+                    v[i] += bv[i];
+                    v[i] = v[i] > 0.f ? v[i] : slope * v[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i] + bv[i]);
+            }
             if (p.dact_mode) {
                 const bf16x8 d = *(const bf16x8*)(ds + o);
 #pragma unroll
@@ -326,12 +415,23 @@ int ga_conv_gemm_supported(const ConvParams& p) {
     return 1;
 }
 
-// GA_GEMM_NBUF=1|2 in the environment pins the LDS buffering of the 128x128 configuration (tuning aid); default: by grid size
+// GA_GEMM_NBUF=1|2|4 in the environment pins the LDS buffering of the 128x128 configuration (tuning aid); default: by grid size
 static int gemm_nbuf_override() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GA_GEMM_NBUF");
-        v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+        v = (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0;
+    }
+    return v;
+}
+
+// grids up to this many workgroups (about one per CU) take the four-buffer pipeline; GA_GEMM_DEEP_MAX overrides (tuning aid)
+static int gemm_deep_max_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_DEEP_MAX");
+        v = e ? atoi(e) : 288;
+        if (v < 0) v = 0;
     }
     return v;
 }
@@ -375,6 +475,6 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
     const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase * (p.ksplit > 1 ? p.ksplit : 1);
     int nbuf = gemm_nbuf_override();
-    if (!nbuf) nbuf = blocks >= 600 ? 1 : 2;
-    return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
+    if (!nbuf) nbuf = blocks >= 600 ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
+    return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
 }

@@ -382,6 +382,7 @@ class PackTrainable(torch.autograd.Function):
         ctx.has_g = gparam is not None
         ctx.save_for_backward(v, gparam, norm)
         ctx.mark_non_differentiable(wp_f, wp_d)
+        ctx.set_materialize_grads(False)  # else autograd zero-fills a weight-sized tensor for each packed output, every backward
         # fp32 gradient carrier: autograd casts a gradient to the dtype of the tensor it belongs to, so the
         # fp32 weight gradient cannot travel on the (possibly bf16) packed weights themselves.
         carrier = _zero_scalar(v.device).expand(wp_f.numel())
