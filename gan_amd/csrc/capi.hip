@@ -18,6 +18,8 @@ int ga_wgrad_gemm_impl(const WgradParams& p, hipStream_t s);
 size_t ga_wgrad_gemm_workspace_elems(const WgradParams& p);
 int ga_thin_conv_supported(const ConvParams& p, int dtype);
 int ga_thin_conv_impl(const ConvParams& p, int dtype, hipStream_t s);
+int ga_wgrad_cin1_mfma_supported(const WgradParams& p);
+int ga_wgrad_cin1_mfma_impl(const WgradParams& p, hipStream_t s);
 int ga_thin_wgrad_supported(const WgradParams& p, int dtype);
 int ga_thin_wgrad_impl(const WgradParams& p, float* dbias, int dtype, int kind, hipStream_t s);
 extern "C" int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s);
@@ -92,6 +94,9 @@ int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {
     if (!p.g || !p.x || !p.dw || p.B <= 0 || p.Lin <= 0 || p.Cin <= 0 || p.M <= 0 || p.Lout < 0 || p.J <= 0) return GA_ERR_ARG;
     if (p.g_stride < 1 || p.LgTot < 1 || p.B > 65535) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
+    // single input channel, caller-padded x: the Toeplitz MFMA kernel (fuses the bias gradient)
+    if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_wgrad_cin1_mfma_supported(p))
+        return ga_wgrad_cin1_mfma_impl(p, s);
     const int thin = ga_thin_wgrad_supported(p, dtype);
     if (thin && impl != GA_IMPL_MFMA && impl != GA_IMPL_MFMA_WINDOW) return ga_thin_wgrad_impl(p, p.dbias, dtype, thin, s);  // fuses the bias gradient
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_wgrad_mfma_supported(p);

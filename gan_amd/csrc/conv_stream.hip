@@ -30,6 +30,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // both counters to zero and serialise the pipeline
 typedef const __attribute__((address_space(1))) bf16x8* gfrag_ptr_t;
 __device__ __forceinline__ bf16x8 ldg_frag(uintptr_t a) { return *(gfrag_ptr_t)a; }
+// the same from a 2-byte-aligned address (single-channel inputs: 8 consecutive samples starting anywhere)
+typedef bf16x8 __attribute__((aligned(2))) bf16x8_u;
+typedef const __attribute__((address_space(1))) bf16x8_u* gfrag_u_ptr_t;
+__device__ __forceinline__ bf16x8 ldg_frag_u(uintptr_t a) { return *(gfrag_u_ptr_t)a; }
 
 __device__ __forceinline__ uintptr_t sel_addr_s(bool ok, uintptr_t a, uintptr_t z) {
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
@@ -71,7 +75,10 @@ __device__ __forceinline__ void divmod_small(int n, int L, float rcpL, int& q, i
     if (rem >= L) { rem -= L; ++q; }
 }
 
-template <int MT, int KS, int NT, bool PRE_ELU, int SIDE>
+// CIN1: single input channel (the discriminators' first conv on the waveform).  K is the tap axis itself: the fragment of
+// lane (n, h) is 8 consecutive SAMPLES x[row(n) + ks*16 + 8h ..], one unaligned 16-byte load.  Padding cannot be applied per
+// 16-byte piece here, so the caller hands in a zero-padded copy of x in which every window is in range (checked on the host).
+template <int MT, int KS, int NT, bool PRE_ELU, int SIDE, bool CIN1 = false>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot, int ng, float rcpL) {
     constexpr int WMR = MT * 32;
     constexpr int EPF = WMR + 4;
@@ -94,6 +101,19 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int k = ks * 16 + h * 8;
+        if (CIN1) {
+            kin[ks] = true;
+            dR[ks] = k;  // (tap_step == 1: the k-th tap is k samples further)
+            cc[ks] = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)  // rows of J (not a multiple of 8) taps: element-wise, once per launch
+                    a[mt][ks][i] = (m < p.M && k + i < Ktot) ? w[(size_t)m * Ktot + k + i] : (__bf16)0.f;
+            }
+            continue;
+        }
         kin[ks] = k < Ktot;
         const int j = k / Cin;
         dR[ks] = j * p.tap_step;
@@ -133,6 +153,11 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 int R = R0 + dR[ks];
+                if (CIN1) {
+                    const bool ok = valid && R >= 0 && R + 8 <= p.Lin;
+                    buf[nt][ks] = ldg_frag_u(sel_addr_s(ok, (uintptr_t)(base + R), zero));
+                    continue;
+                }
                 if (R < 0 && p.pad_mode == 1) R = -R;
                 const bool ok = valid && kin[ks] && R >= 0 && R < p.Lin;
                 buf[nt][ks] = ldg_frag(sel_addr_s(ok, (uintptr_t)(base + (size_t)R * Cin + cc[ks]), zero));
@@ -242,6 +267,15 @@ static int stream_side(const ConvParams& p) {
     return SIDE_NONE;
 }
 
+// single-channel form: 1 <= J <= 32 taps one sample apart, and every 8-sample piece any lane touches inside its item
+static int stream_cin1_ok(const ConvParams& p) {
+    if (p.Cin != 1 || p.tap_step != 1 || p.J < 1 || p.J > 32 || p.in_stride < 1 || p.t0 != 0 || p.pad_mode != 0) return 0;
+    if (p.pre_act != GA_ACT_NONE || p.res || p.dact_mode || p.dact_src) return 0;
+    const int ks = (p.J + 15) / 16;
+    if (p.off0 < 0 || (long)(p.Lout - 1) * p.in_stride + p.off0 + ks * 16 > p.Lin) return 0;
+    return 1;
+}
+
 int ga_conv_stream_supported(const ConvParams& p) {
     if (p.pre_act != GA_ACT_NONE && p.pre_act != GA_ACT_ELU) return 0;
     if (p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
@@ -250,10 +284,16 @@ int ga_conv_stream_supported(const ConvParams& p) {
     if (p.accumulate || p.out_f32 || stream_side(p) < 0) return 0;
     if (p.pre_act == GA_ACT_ELU && p.dact_mode) return 0;  // (not instantiated: a forward fuses ELU, a data gradient its derivative)
     if (p.nphase != 1 || p.ksplit > 1) return 0;
-    if (p.Cin % 8 || p.Cin < 8 || p.M % 8 || p.M < 8 || p.M > 64 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if (p.M % 8 || p.M < 8 || p.M > 64 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if (p.Cin == 1) {
+        if (!stream_cin1_ok(p)) return 0;
+    } else if (p.Cin % 8 || p.Cin < 8) {
+        return 0;
+    }
     if ((long)p.J * p.Cin > STREAM_KMAX) return 0;
     if (p.y_batch_elems < 0 || (p.y_batch_elems > 0 && (p.y_batch_elems % 8 || (long)p.y_batch_elems > (long)p.LoutTot * p.M))) return 0;
-    if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
+    if (((uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.dact_src | (uintptr_t)p.bias) & 15) return 0;
+    if (p.Cin == 1 ? (((uintptr_t)p.x | (uintptr_t)p.w) & 1) : (((uintptr_t)p.x | (uintptr_t)p.w) & 15)) return 0;
     if ((long)p.B * p.Lout > (1L << 30) || p.B > (1 << 18)) return 0;
     return 1;
 }
@@ -279,8 +319,22 @@ static int launch_stream(const ConvParams& p, hipStream_t s) {
     return GA_OK;
 }
 
+template <int MT, int KS>
+static int launch_stream_cin1(const ConvParams& p, hipStream_t s) {
+    constexpr int NT = 4;
+    const int Ntot = p.B * p.Lout;
+    const int ng = (Ntot + 32 * NT - 1) / (32 * NT);
+    if (ng <= 0) return GA_OK;
+    int grid = (ng + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    conv_stream_kernel<MT, KS, NT, false, SIDE_NONE, true><<<grid, 256, 0, s>>>(p, Ntot, ng, 1.0f / (float)p.Lout);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
 template <int MT>
 static int launch_stream_mt(const ConvParams& p, hipStream_t s) {
+    if (p.Cin == 1) return p.J <= 16 ? launch_stream_cin1<MT, 1>(p, s) : launch_stream_cin1<MT, 2>(p, s);
     const int ks = (p.J * p.Cin + 15) / 16;
     if (ks <= 1) return launch_stream<MT, 1, 4>(p, s);
     if (ks <= 2) return launch_stream<MT, 2, MT == 1 ? 4 : 2>(p, s);

@@ -542,7 +542,9 @@ static int thin_wgrad_t(const WgradParams& p, float* dbias, int kind, hipStream_
         const int chunks_per_b = (p.Lout + WG1_ROWS - 1) / WG1_ROWS;
         wgrad_cin1_kernel<T><<<p.B * chunks_per_b, 256, 0, s>>>(p, dbias, chunks_per_b);
     } else {
-        int rows_per_block = 256;
+        // short inputs (D's last conv: 118..469 rows per item): 32 rows per block, so that the grid fills the chip and a
+        // thread's chain of dependent g loads is a handful of rows long
+        int rows_per_block = (long)p.Lin * p.B <= 65536 ? 32 : 256;
         int gx = (p.Lin + rows_per_block - 1) / rows_per_block;
         if (gx > 4096) { gx = 4096; rows_per_block = (p.Lin + gx - 1) / gx; }
         wgrad_m1_kernel<T><<<dim3(gx, p.B), 256, 0, s>>>(p, dbias, rows_per_block);

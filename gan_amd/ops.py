@@ -210,6 +210,29 @@ def set_conv_impl(impl: int) -> None:
     _IMPL = impl
 
 
+# ---- single-input-channel layers (the discriminators' first conv on the waveform) ---------------------------------
+# Their MFMA kernels read 8 consecutive samples per 16-byte piece, so zero padding cannot be applied piece-wise: the input
+# is copied once into a zero-padded buffer (a few MB) in which every window is in range, and the problem is restated on it.
+CIN1_MFMA = True
+_CIN1_BACK = 64      # zero samples behind each item (>= 32-step round-up + 16 taps + one 8-sample piece)
+_CIN1_CACHE: list = []  # [(x, version, padded)] most recent first; the forward's copy serves the weight gradient too
+
+
+def _cin1_padded(g: ConvGeom, x: Tensor):
+    """(padded x, front) when the single-channel MFMA kernels apply to conv layer g on x, else (None, 0)."""
+    if not (CIN1_MFMA and g.kind == "conv" and g.cin == 1 and g.dilation == 1 and g.stride == 1 and g.k <= 15
+            and g.cout % 16 == 0 and g.cout <= 64 and x.dtype == torch.bfloat16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA)):
+        return None, 0
+    key = (x.data_ptr(), x._version, tuple(x.shape), g.padding)
+    for ent in _CIN1_CACHE:  # (an entry keeps its source tensor alive, so its address cannot be reused while cached)
+        if ent[1] == key:
+            return ent[2], g.padding
+    xp = torch.nn.functional.pad(x, (0, 0, g.padding, _CIN1_BACK))
+    _CIN1_CACHE.insert(0, (x, key, xp))
+    del _CIN1_CACHE[4:]
+    return xp, g.padding
+
+
 def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None,
                  out_f32: bool = False) -> Tensor:
     B, lin, cin = x.shape
@@ -218,6 +241,11 @@ def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre
     p.pre_act, p.post_act = pre_act, post_act
     p.out_f32 = 1 if (out_f32 and x.dtype == torch.bfloat16) else 0
     y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=torch.float32 if p.out_f32 else x.dtype)
+    if not pre_act and res is None and not p.out_f32:
+        xp, front = _cin1_padded(g, x)
+        if xp is not None:  # the same problem on the zero-padded copy: no row is ever out of range
+            p.Lin, p.off0 = xp.shape[1], p.off0 + front
+            x = xp
     _launch_conv(p, x, wp, y, bias=bias, res=res, impl=_IMPL)
     return y
 
@@ -254,8 +282,11 @@ def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
     buf = zeros_f32(ndw + (g.cout if want_bias else 0), x.device)  # one buffer for both
     dw = buf[:ndw].view(g.cout, g.k, g.cin)
     db = buf[ndw:] if want_bias else None
+    xp, front = _cin1_padded(g, x)
+    if xp is not None:
+        x = xp
     _fill(p, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=L.ptr(db), B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout,
-          Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation, off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
+          Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation, off0=front - g.padding, LgTot=lout, g_stride=1, g_phase=0)
     nws = L.lib().ga_wgrad_workspace_elems(C.byref(p), L.dt(x), _IMPL) if WGRAD_SLABS else 0
     if nws:
         ws = torch.empty((nws,), device=x.device, dtype=torch.float32)  # per-slice partial tiles (plain stores, no atomics)

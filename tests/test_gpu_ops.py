@@ -276,6 +276,38 @@ def test_tiled_pack_and_unpack_match_layout_definition(shape):
             assert torch.equal(dw.cpu(), want), (mode, acc)
 
 
+@pytest.mark.parametrize("shape", [(3, 4001, 32, 15), (2, 1000, 64, 7), (5, 130, 16, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_single_channel_mfma_kernels_match_direct(shape):
+    """D's first conv (one input channel): forward on the streaming MFMA kernel and weight + bias gradient on the Toeplitz
+    MFMA kernel, both on a zero-padded copy of the waveform, against the direct kernels on the unpadded input."""
+    B, Ln, M, K = shape
+    g = ConvGeom("conv", 1, M, K, 1, K // 2, 1)
+    torch.manual_seed(40)
+    x = torch.randn(B, Ln, 1, device=DEV).bfloat16()
+    w = torch.randn(M, 1, K, device=DEV) / K ** 0.5
+    bias = torch.randn(M, device=DEV)
+    ga = torch.randn(B, Ln, M, device=DEV).bfloat16()
+    wf = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16)
+    outs = {}
+    for impl in (L.IMPL_AUTO, L.IMPL_DIRECT):
+        ops.set_conv_impl(impl)
+        try:
+            ops.PROFILE = []
+            y = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU)
+            kid = ops.PROFILE[0][0]
+            ops.PROFILE = None
+            dw, db = ops.conv_wgrad(g, ga, x, want_bias=True)
+            outs[impl] = (y.float().cpu(), dw.clone().cpu(), db.clone().cpu())
+        finally:
+            ops.PROFILE = None
+            ops.set_conv_impl(L.IMPL_AUTO)
+        if impl == L.IMPL_AUTO:
+            assert kid == L.KERNEL_STREAM, kid
+    close(outs[L.IMPL_AUTO][0], outs[L.IMPL_DIRECT][0], 1e-2, "cin1 fwd")
+    close(outs[L.IMPL_AUTO][1], outs[L.IMPL_DIRECT][1], 2e-3, "cin1 dw")
+    close(outs[L.IMPL_AUTO][2], outs[L.IMPL_DIRECT][2], 2e-3, "cin1 db")
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
