@@ -536,15 +536,84 @@ int ga_thin_wgrad_supported(const WgradParams& p, int dtype) {
     return 0;
 }
 
+// The same for wide inputs (D's last conv: 1024 channels, a few hundred rows per item): one workgroup per 32 channels walks
+// EVERY row (64 row lanes x 4 channel parts), so each output is summed inside one workgroup -- no contended atomics -- and
+// the loop is branch-free and unrolled so that a thread's loads are in flight together.  in_stride == 1.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_m1_wide_kernel(WgradParams p, float* __restrict__ dbias) {
+    __shared__ float red[256 * 9];
+    const T* __restrict__ g = (const T*)p.g;
+    const T* __restrict__ x = (const T*)p.x;
+    const int part = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c0 = blockIdx.x * 32 + part * 8;
+    const long nrows = (long)p.B * p.Lin;
+    float acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    float gsum = 0.f;
+    for (long n0 = rl; n0 < nrows; n0 += 64 * 4) {
+        Vec8<T> xv[4];
+        float gv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long n = n0 + u * 64;
+            const long nc = n < nrows ? n : nrows - 1;
+            xv[u].load(x + nc * p.Cin + c0);
+            const int b = (int)(nc / p.Lin), R = (int)(nc - (long)b * p.Lin);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = R - j * p.tap_step - p.off0;
+                const bool ok = j < p.J && n < nrows && t >= 0 && t < p.Lout;
+                const int tc = t < 0 ? 0 : (t >= p.Lout ? p.Lout - 1 : t);
+                const float v = (float)g[(size_t)b * p.LgTot + (size_t)tc * p.g_stride + p.g_phase];
+                gv[u][j] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(gv[u][j], xv[u].v[i], acc[j][i]);
+    }
+    // sum over the 64 row lanes: per tap, [256 threads][8 channels] through LDS
+    for (int j = 0; j < p.J && j < 8; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x * 9 + i] = acc[j][i];
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int pt = threadIdx.x >> 3, i = threadIdx.x & 7;
+            float sum = 0.f;
+            for (int l = 0; l < 64; ++l) sum += red[(l * 4 + pt) * 9 + i];
+            atomicAdd(&p.dw[(size_t)j * p.Cin + blockIdx.x * 32 + threadIdx.x], sum);
+        }
+    }
+    if (dbias && blockIdx.x == 0) {
+        __syncthreads();
+        for (long i = threadIdx.x; i < (long)p.B * p.Lout; i += 256) {
+            const long b = i / p.Lout, t = i - b * p.Lout;
+            gsum += (float)g[(size_t)b * p.LgTot + (size_t)t * p.g_stride + p.g_phase];
+        }
+        gsum = block_sum(gsum, red);
+        if (threadIdx.x == 0) atomicAdd(dbias, gsum);
+    }
+}
+
 template <typename T>
 static int thin_wgrad_t(const WgradParams& p, float* dbias, int kind, hipStream_t s) {
     if (kind == 1) {
         const int chunks_per_b = (p.Lout + WG1_ROWS - 1) / WG1_ROWS;
         wgrad_cin1_kernel<T><<<p.B * chunks_per_b, 256, 0, s>>>(p, dbias, chunks_per_b);
     } else {
-        // short inputs (D's last conv: 118..469 rows per item): 32 rows per block, so that the grid fills the chip and a
-        // thread's chain of dependent g loads is a handful of rows long
-        int rows_per_block = (long)p.Lin * p.B <= 65536 ? 32 : 256;
+        if (p.Cin >= 256 && p.Cin % 32 == 0 && p.in_stride == 1 && (long)p.B * p.Lin < (1L << 30)) {
+            wgrad_m1_wide_kernel<T><<<p.Cin / 32, 256, 0, s>>>(p, dbias);
+            GA_CHECK_LAUNCH();
+            return GA_OK;
+        }
+        int rows_per_block = 256;
         int gx = (p.Lin + rows_per_block - 1) / rows_per_block;
         if (gx > 4096) { gx = 4096; rows_per_block = (p.Lin + gx - 1) / gx; }
         wgrad_m1_kernel<T><<<dim3(gx, p.B), 256, 0, s>>>(p, dbias, rows_per_block);
