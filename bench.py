@@ -108,7 +108,11 @@ def main():
                     "stream (gan_amd/prefetch.py; measured slower on MI355X: the two launch-bound chains do not overlap)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
+    ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass instead of after it")
     args = ap.parse_args()
+    # the contract is ONE line on stdout: libraries that print banners there (RCCL prints its version at init) go to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,6 +131,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         from gan_amd.dp import DataParallel
         dp = DataParallel()
+        dp.overlap = bool(args.dp_overlap)
 
     from gan_amd import ops
     from gan_amd.lab3_codec_models import CodecTrainWeights
@@ -229,7 +234,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_sample_batch, args.cpu_iters)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dp is not None:
         torch.distributed.destroy_process_group()
 

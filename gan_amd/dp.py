@@ -4,7 +4,7 @@ MI355X-side design:
 
   * the batch is sharded across ranks; G, D, decoder and both optimizers are replicated;
   * gradients live in the optimizer's flat fp32 buffer (gan_amd/optim.py) and are SUM-all-reduced in contiguous
-    buckets (default 16 MiB: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large messages beat many
+    buckets (default 64 MiB: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large messages beat many
     small ones); 1/world_size is folded into the fused AdamW kernel (grad_scale), so no separate scaling pass;
   * buckets are issued asynchronously in reverse parameter order (the order backward produces them) and waited for
     only right before the clip+AdamW kernel;
@@ -37,8 +37,84 @@ class _AllReduceSums(torch.autograd.Function):
         return g * float(ctx.world), None
 
 
+class _OverlapState:
+    """Bucket bookkeeping of one optimizer for DataParallel.begin_backward / finish_backward."""
+
+    def __init__(self, dp: "DataParallel", opt):
+        self.dp, self.opt = dp, opt
+        self.slices = dp.bucket_slices(opt.numel)
+        self.bucket_of: List[List[int]] = []
+        self.need = [0] * len(self.slices)
+        for p, off in zip(opt.params, opt.offsets):
+            lo, hi = off, off + p.numel()
+            bs = [b for b, (a, e) in enumerate(self.slices) if lo < e and hi > a]
+            self.bucket_of.append(bs)
+            for b in bs:
+                self.need[b] += 1
+        self.members = [[i for i, bs in enumerate(self.bucket_of) if b in bs] for b in range(len(self.slices))]
+        self.copied: List[bool] = []
+        self.cuda = opt.flat_g.is_cuda
+        self.comm = torch.cuda.Stream(device=opt.flat_g.device) if self.cuda else None
+        self.active = False
+        self.left: List[int] = []
+        self.sent: List[bool] = []
+        self.works: list = []
+
+    def begin(self) -> None:
+        self.opt.flat_g.zero_()
+        self.left = list(self.need)
+        self.copied = [False] * len(self.opt.params)
+        self.sent = [False] * len(self.slices)
+        self.works = []
+        self.active = True
+
+    def on_grad(self, i: int) -> None:
+        if not self.active:
+            return
+        for b in self.bucket_of[i]:
+            self.left[b] -= 1
+            if self.left[b] == 0:
+                self._send(b)
+
+    def _send(self, b: int) -> None:
+        if self.sent[b]:
+            return
+        self.sent[b] = True
+        # one fused copy of the bucket's gradients into the flat buffer.  A parameter that straddles two buckets is copied
+        # with the first of them to go; the other one cannot have gone earlier, because it was waiting for this parameter too.
+        src, dst = [], []
+        for i in self.members[b]:
+            if not self.copied[i]:
+                self.copied[i] = True
+                g = self.opt.params[i].grad
+                if g is not None and g.data_ptr() != self.opt.grad_views[i].data_ptr():
+                    src.append(g)
+                    dst.append(self.opt.grad_views[i])
+        if src:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+        a, e = self.slices[b]
+        chunk = self.opt.flat_g[a:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()  # the copies into this bucket are on the current (main) stream
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True))
+
+    def finish(self) -> None:
+        self.active = False
+        for b in range(len(self.slices)):
+            self._send(b)
+        for w in self.works:
+            w.wait()  # (RCCL: the current stream waits; no host synchronisation)
+        self.works = []
+
+
 class DataParallel:
-    def __init__(self, group=None, bucket_bytes: int = 16 << 20, exact_stft: bool = True):
+    def __init__(self, group=None, bucket_bytes: int = 64 << 20, exact_stft: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -46,6 +122,10 @@ class DataParallel:
         self.world_size = dist.get_world_size(group)
         self.bucket_elems = max(1, int(bucket_bytes) // 4)
         self.exact_stft = exact_stft
+        # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward).  Off by default:
+        # measured on one MI355X (one-rank RCCL group, so the collective is a device copy) the side-stream collectives
+        # cost the backward pass 1.5 ms per iteration, more than the ~1 ms of xGMI all-reduce they could hide at 8 ranks.
+        self.overlap = False
 
     def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
         """Contiguous [start, end) slices of the flat gradient buffer, last parameters first."""
@@ -64,6 +144,28 @@ class DataParallel:
             works.append(dist.all_reduce(opt.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
+        opt.grad_scale = 1.0 / float(self.world_size)
+
+    # ---- all-reduce overlapped with the backward pass --------------------------------------------------------------
+    # Every parameter gets a post-accumulate-grad hook that copies its finished gradient into the optimizer's flat buffer
+    # and counts it off against the bucket(s) it lies in; the moment a bucket is complete its SUM all-reduce is issued on a
+    # side stream, while autograd keeps producing the earlier layers' gradients on the main stream (backward yields the
+    # LAST parameters first, so the highest bucket -- D blocks.4, most of the bytes -- goes out first).  finish_backward
+    # issues whatever is left (parameters that received no gradient stay zero) and makes the main stream wait.
+    def attach(self, opt) -> None:
+        if getattr(opt, "_dp_overlap", None) is not None:
+            return
+        st = _OverlapState(self, opt)
+        opt._dp_overlap = st
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i, st=st: st.on_grad(i))
+
+    def begin_backward(self, opt) -> None:
+        self.attach(opt)
+        opt._dp_overlap.begin()
+
+    def finish_backward(self, opt) -> None:
+        opt._dp_overlap.finish()
         opt.grad_scale = 1.0 / float(self.world_size)
 
     def stft_sum_hook(self, sums: torch.Tensor, count: float):

@@ -206,6 +206,20 @@ def latent_losses(q_hat: torch.Tensor, q_src: torch.Tensor, delta_budget: float)
     return l1, cont, budget
 
 
+def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
+    """loss.backward() with the gradients landing in opt.flat_g; under data parallelism the buckets of the flat buffer are
+    all-reduced while the backward pass is still producing the earlier layers' gradients (gan_amd/dp.py)."""
+    if dp is not None and getattr(dp, "overlap", False):
+        dp.begin_backward(opt)
+        loss.backward()
+        dp.finish_backward(opt)
+        return
+    loss.backward()
+    opt.gather_grads()
+    if dp is not None:
+        dp.allreduce_flat(opt)
+
+
 def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTranslator,
                           discriminator: MultiScaleWaveDiscriminator, codec, opt_g: FusedAdamW, opt_d: FusedAdamW,
                           q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
@@ -264,11 +278,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
             r1 = r1_penalty_and_grads(discriminator, x_real, real_outs, 0.5 * float(stage_cfg.r1_gamma))
             out["r1"] = r1
             loss_d_total = loss_d_total + 0.5 * float(stage_cfg.r1_gamma) * r1
-        loss_d.backward()
         opt_d.max_grad_norm = float(stage_cfg.d_grad_clip_norm)
-        opt_d.gather_grads()
-        if dp is not None:
-            dp.allreduce_flat(opt_d)
+        _backward_and_reduce(loss_d, opt_d, dp)
         opt_d.step(grads_gathered=True)
         out["loss_d"] = loss_d_total
         out["d_grad_norm"] = opt_d.last_grad_norm
@@ -313,11 +324,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
               + float(w.latent_continuity) * loss_lat_cont + float(w.mrstft) * loss_mrstft
               + float(w.mode_seeking) * loss_ms + float(w.delta_budget) * loss_delta_budget)
     opt_g.zero_grad(set_to_none=True)
-    loss_g.backward()
     opt_g.max_grad_norm = float(stage_cfg.g_grad_clip_norm)
-    opt_g.gather_grads()
-    if dp is not None:
-        dp.allreduce_flat(opt_g)
+    _backward_and_reduce(loss_g, opt_g, dp)
     opt_g.step(grads_gathered=True)
 
     out.update(loss_g=loss_g.detach(), loss_adv=loss_adv.detach(), loss_fm=loss_fm.detach(),

@@ -45,6 +45,38 @@ def _worker(rank, world, port, q):
         dp.broadcast_params(opt)
         assert torch.equal(opt.flat_p, torch.full((n,), 7.0))
 
+        # all-reduce overlapped with backward: hooks copy each finished gradient into the flat buffer and send a bucket as
+        # soon as it is complete; a parameter straddling two buckets and one that receives no gradient are both covered
+        class _Opt2:
+            pass
+        torch.manual_seed(3)
+        o2 = _Opt2()
+        o2.params = [torch.nn.Parameter(torch.randn(700)), torch.nn.Parameter(torch.randn(30, 50)),
+                     torch.nn.Parameter(torch.randn(9)), torch.nn.Parameter(torch.randn(1200))]
+        o2.offsets, tot = [], 0
+        for prm in o2.params:
+            o2.offsets.append(tot)
+            tot += (prm.numel() + 3) // 4 * 4
+        o2.numel = tot
+        o2.flat_g = torch.full((tot,), 5.0)  # stale contents must not survive
+        o2.grad_views = [o2.flat_g[off:off + prm.numel()].view_as(prm) for prm, off in zip(o2.params, o2.offsets)]
+        o2.grad_scale = 1.0
+        for rep in range(2):  # the hooks stay registered: a second backward must start clean
+            for prm in o2.params:
+                prm.grad = None
+            loss = (o2.params[0] * (rank + 1.0)).sum() + (o2.params[1] ** 2).sum() * (rank + 2.0) + (o2.params[3] * 0.5).sum()
+            dp.begin_backward(o2)
+            loss.backward()
+            dp.finish_backward(o2)
+            assert o2.grad_scale == 0.5
+            want = [torch.full((700,), 3.0), 2.0 * o2.params[1].detach() * 5.0, torch.zeros(9), torch.full((1200,), 1.0)]
+            for v, wv in zip(o2.grad_views, want):
+                assert torch.allclose(v, wv.view_as(v), rtol=1e-6), rep
+        # outside begin/finish the hooks are inert
+        o2.flat_g.fill_(-1.0)
+        (o2.params[0].sum()).backward()
+        assert torch.equal(o2.flat_g, torch.full((tot,), -1.0))
+
         # exact global-batch spectral convergence: ratio of all-reduced sums == single-process value on the full batch
         torch.manual_seed(0)
         x = torch.randn(4, 4096)
