@@ -109,13 +109,24 @@ class CodecLatentTranslator(nn.Module):
             zs = zs + torch.randn_like(zs) * float(style_jitter_std)
         cond = torch.cat([z_content, zs, noise], dim=1).float()
 
+        # All 2*n_blocks FiLM MLPs read the same cond vector: their first Linear layers are ONE GEMM on the concatenated
+        # weights and their second layers one batched GEMM, instead of 4*n_blocks tiny library launches (and as many again
+        # in the backward pass).  Same arithmetic per output element; autograd routes the gradients back to each module.
+        films = [f for blk in self.blocks for f in (blk.film1, blk.film2)]
+        n_f = len(films)
+        hid = F.silu(F.linear(cond, torch.cat([f.proj[0].weight for f in films], 0), torch.cat([f.proj[0].bias for f in films], 0)))
+        hid = hid.view(b, n_f, -1).transpose(0, 1)                                   # [n_f, B, 2C]
+        w2 = torch.stack([f.proj[2].weight for f in films], 0).transpose(1, 2)       # [n_f, 2C(in), 2C(out)]
+        b2 = torch.stack([f.proj[2].bias for f in films], 0).unsqueeze(1)            # [n_f, 1, 2C]
+        abs_ = torch.baddbmm(b2, hid, w2).unbind(0)                                  # n_f x [B, 2C], contiguous
+
         q = _to_nlc(q_src, dtype)
         h = _conv_train(q, self.in_proj, self._g_in, dtype)
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
             r = _conv_train(h, blk.conv1, blk.g1, dtype)
-            r = ops.GnFilmAct.apply(r, blk.norm1.weight, blk.norm1.bias, blk.film1.ab(cond), None, 8, L.ACT_SILU, blk.norm1.eps)
+            r = ops.GnFilmAct.apply(r, blk.norm1.weight, blk.norm1.bias, abs_[2 * i], None, 8, L.ACT_SILU, blk.norm1.eps)
             r = _conv_train(r, blk.conv2, blk.g2, dtype)
-            h = ops.GnFilmAct.apply(r, blk.norm2.weight, blk.norm2.bias, blk.film2.ab(cond), h, 8, L.ACT_SILU, blk.norm2.eps)
+            h = ops.GnFilmAct.apply(r, blk.norm2.weight, blk.norm2.bias, abs_[2 * i + 1], h, 8, L.ACT_SILU, blk.norm2.eps)
         h = ops.GnFilmAct.apply(h, self.out_norm.weight, self.out_norm.bias, None, None, 8, L.ACT_SILU, self.out_norm.eps)
         raw = _conv_train(h, self.out_proj, self._g_out, dtype)
         if self.direct_output:
