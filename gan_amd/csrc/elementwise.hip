@@ -643,12 +643,22 @@ __device__ __forceinline__ float red_df(int op, float a, float b) {
     }
 }
 
+// 16 bytes per lane per trip when the operands are 16-byte aligned (vec != 0); scalar elements otherwise and for the tail
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op,
-                                                      float scale, float* __restrict__ out) {
+                                                      float scale, float* __restrict__ out, int vec) {
     __shared__ float red[16];
+    constexpr int EV = 16 / sizeof(T);
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    const size_t nv = vec ? n / EV : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        const Pack16<T> av = ((const Pack16<T>*)a)[i];
+        Pack16<T> bv;
+        if (b) bv = ((const Pack16<T>*)b)[i];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) s += red_f(op, (float)av.v[e], b ? (float)bv.v[e] : 0.f);
+    }
+    for (size_t i = nv * EV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         s += red_f(op, (float)a[i], b ? (float)b[i] : 0.f);
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s * scale);
@@ -657,9 +667,24 @@ __global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, co
 // ga[i] (+)= coef[0] * scale * d f / d a
 template <typename T>
 __global__ void reduce_grad_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op, const float* __restrict__ coef,
-                                   float scale, T* __restrict__ ga, int accumulate) {
+                                   float scale, T* __restrict__ ga, int accumulate, int vec) {
+    constexpr int EV = 16 / sizeof(T);
     const float c = coef[0] * scale;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t nv = vec ? n / EV : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        const Pack16<T> av = ((const Pack16<T>*)a)[i];
+        Pack16<T> bv, gv, o;
+        if (b) bv = ((const Pack16<T>*)b)[i];
+        if (accumulate) gv = ((const Pack16<T>*)ga)[i];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            float v = c * red_df(op, (float)av.v[e], b ? (float)bv.v[e] : 0.f);
+            if (accumulate) v += (float)gv.v[e];
+            o.v[e] = (T)v;
+        }
+        ((Pack16<T>*)ga)[i] = o;
+    }
+    for (size_t i = nv * EV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = c * red_df(op, (float)a[i], b ? (float)b[i] : 0.f);
         if (accumulate) v += (float)ga[i];
         ga[i] = (T)v;
@@ -973,8 +998,10 @@ int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, hipStrea
 int ga_reduce(const void* a, const void* b, int dtype, size_t n, int op, float scale, float* out, hipStream_t s) {
     if (!a || !out || op < 0 || op > 4 || (op == GA_RED_ABSDIFF && !b)) return GA_ERR_ARG;
     if (n == 0) return GA_OK;
-    DISPATCH_T(dtype, (reduce_kernel<float><<<grid_for(n, 256, 1024), 256, 0, s>>>((const float*)a, (const float*)b, n, op, scale, out)),
-               (reduce_kernel<bf16_t><<<grid_for(n, 256, 1024), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, scale, out)));
+    const int vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const size_t work = vec ? n / (dtype == GA_DTYPE_BF16 ? 8 : 4) + 1 : n;
+    DISPATCH_T(dtype, (reduce_kernel<float><<<grid_for(work, 256, 1024), 256, 0, s>>>((const float*)a, (const float*)b, n, op, scale, out, vec)),
+               (reduce_kernel<bf16_t><<<grid_for(work, 256, 1024), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, scale, out, vec)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
@@ -982,8 +1009,10 @@ int ga_reduce_grad(const void* a, const void* b, int dtype, size_t n, int op, co
                    int accumulate, hipStream_t s) {
     if (!a || !coef || !ga || op < 0 || op > 4 || (op == GA_RED_ABSDIFF && !b)) return GA_ERR_ARG;
     if (n == 0) return GA_OK;
-    DISPATCH_T(dtype, (reduce_grad_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)a, (const float*)b, n, op, coef, scale, (float*)ga, accumulate)),
-               (reduce_grad_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, coef, scale, (bf16_t*)ga, accumulate)));
+    const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 15) == 0;
+    const size_t work = vec ? n / (dtype == GA_DTYPE_BF16 ? 8 : 4) + 1 : n;
+    DISPATCH_T(dtype, (reduce_grad_kernel<float><<<grid_for(work), 256, 0, s>>>((const float*)a, (const float*)b, n, op, coef, scale, (float*)ga, accumulate, vec)),
+               (reduce_grad_kernel<bf16_t><<<grid_for(work), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, coef, scale, (bf16_t*)ga, accumulate, vec)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -206,41 +206,35 @@ class MultiScaleWaveDiscriminator(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # losses (reference lab3_codec_models.py:171-215); means are sums from the reduction kernels / numel
 def hinge_d_loss(real_logits: torch.Tensor, fake_logits: torch.Tensor) -> torch.Tensor:
-    return (ops.reduce_sum(real_logits, None, L.RED_RELU1M) / real_logits.numel()
-            + ops.reduce_sum(fake_logits, None, L.RED_RELU1P) / fake_logits.numel())
+    return (ops.reduce_sum(real_logits, None, L.RED_RELU1M, 1.0 / real_logits.numel())
+            + ops.reduce_sum(fake_logits, None, L.RED_RELU1P, 1.0 / fake_logits.numel()))
 
 
 def hinge_g_loss(fake_logits: torch.Tensor) -> torch.Tensor:
-    return -ops.reduce_sum(fake_logits, None, L.RED_SUM) / fake_logits.numel()
+    return ops.reduce_sum(fake_logits, None, L.RED_SUM, -1.0 / fake_logits.numel())
 
 
 def feature_matching_loss(real_feats: Sequence[torch.Tensor], fake_feats: Sequence[torch.Tensor]) -> torch.Tensor:
-    loss = torch.zeros((), device=fake_feats[0].device)
-    for a, b in zip(real_feats, fake_feats):
-        # F.l1_loss(a.detach(), b): the gradient goes to the fake features only
-        loss = loss + ops.reduce_sum(b, a.detach(), L.RED_ABSDIFF) / b.numel()
-    return loss / max(1, len(fake_feats))
+    # F.l1_loss(a.detach(), b): the gradient goes to the fake features only; 1/numel is applied inside the reduction kernel
+    terms = [ops.reduce_sum(b, a.detach(), L.RED_ABSDIFF, 1.0 / b.numel()) for a, b in zip(real_feats, fake_feats)]
+    if not terms:
+        return torch.zeros(())
+    return torch.stack(terms).sum() / max(1, len(fake_feats))
 
 
 def multiscale_hinge_d_loss(real_outs, fake_outs) -> torch.Tensor:
-    loss = torch.zeros((), device=real_outs[0][0].device)
-    for (real_logits, _), (fake_logits, _) in zip(real_outs, fake_outs):
-        loss = loss + hinge_d_loss(real_logits, fake_logits)
-    return loss / max(1, len(real_outs))
+    terms = [hinge_d_loss(real_logits, fake_logits) for (real_logits, _), (fake_logits, _) in zip(real_outs, fake_outs)]
+    return torch.stack(terms).sum() / max(1, len(real_outs))
 
 
 def multiscale_hinge_g_loss(fake_outs) -> torch.Tensor:
-    loss = torch.zeros((), device=fake_outs[0][0].device)
-    for fake_logits, _ in fake_outs:
-        loss = loss + hinge_g_loss(fake_logits)
-    return loss / max(1, len(fake_outs))
+    terms = [hinge_g_loss(fake_logits) for fake_logits, _ in fake_outs]
+    return torch.stack(terms).sum() / max(1, len(fake_outs))
 
 
 def multiscale_feature_matching_loss(real_outs, fake_outs) -> torch.Tensor:
-    loss = torch.zeros((), device=fake_outs[0][0].device)
-    for (_, rf), (_, ff) in zip(real_outs, fake_outs):
-        loss = loss + feature_matching_loss(rf, ff)
-    return loss / max(1, len(real_outs))
+    terms = [feature_matching_loss(rf, ff) for (_, rf), (_, ff) in zip(real_outs, fake_outs)]
+    return torch.stack(terms).sum() / max(1, len(real_outs))
 
 
 @dataclass

@@ -169,7 +169,7 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
         total = total + sc + lm
         used += 1
     if used == 0:
-        return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF) / wav_pred.numel()
+        return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF, 1.0 / wav_pred.numel())
     return total / float(used)
 
 
@@ -316,7 +316,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         noise2 = noise2 * float(stage_cfg.mode_seeking_noise_scale)
         q_hat2 = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise2,
                            style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
-        num = ops.reduce_sum(q_hat, q_hat2, L.RED_ABSDIFF) / q_hat.numel()  # latent-space mode seeking (:567-571)
+        num = ops.reduce_sum(q_hat, q_hat2, L.RED_ABSDIFF, 1.0 / q_hat.numel())  # latent-space mode seeking (:567-571)
         den = torch.mean(torch.abs(noise - noise2)).clamp_min(1e-5)
         loss_ms = F.relu(float(stage_cfg.mode_seeking_target) - num / den)
 

@@ -660,7 +660,7 @@ class ReduceSum(torch.autograd.Function):
     """sum_i f(a_i, b_i) as a 1-element fp32 tensor; gradient flows to `a` (and, for |a-b|, to `b` if it needs one)."""
 
     @staticmethod
-    def forward(ctx, a, b, op: int):
+    def forward(ctx, a, b, op: int, scale: float = 1.0):
         L.require_cuda(a)
         af, perm = _flat_view(a)
         bf = None
@@ -670,18 +670,18 @@ class ReduceSum(torch.autograd.Function):
                 bf = (b.permute(0, 2, 1) if perm else b).contiguous()
             assert bf.shape == af.shape and bf.dtype == af.dtype, "operands must share shape and dtype"
         out = zeros_f32(1, a.device)
-        L.check(L.lib().ga_reduce(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), op, 1.0, out.data_ptr(), L.stream()), "ga_reduce")
+        L.check(L.lib().ga_reduce(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), op, float(scale), out.data_ptr(), L.stream()), "ga_reduce")
         ctx.save_for_backward(af, bf)
-        ctx.op = op
+        ctx.op, ctx.scale = op, float(scale)
         ctx.permuted = perm
-        return out
+        return out.view(())  # 0-dim: indexing a 1-element result would add a select + its zero-fill backward per loss term
 
     @staticmethod
     def backward(ctx, gout):
         af, bf = ctx.saved_tensors
         ga = torch.empty_like(af)
         gout = gout.contiguous().float()
-        L.check(L.lib().ga_reduce_grad(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), ctx.op, gout.data_ptr(), 1.0,
+        L.check(L.lib().ga_reduce_grad(af.data_ptr(), L.ptr(bf), L.dt(af), af.numel(), ctx.op, gout.data_ptr(), ctx.scale,
                                        ga.data_ptr(), 0, L.stream()), "ga_reduce_grad")
         if ctx.permuted:
             ga = ga.permute(0, 2, 1)
@@ -690,11 +690,12 @@ class ReduceSum(torch.autograd.Function):
             if ctx.op != L.RED_ABSDIFF:
                 raise NotImplementedError("gradient w.r.t. the second operand exists for |a-b| only")
             gb = ga.neg()
-        return ga, gb, None
+        return ga, gb, None, None
 
 
-def reduce_sum(a: Tensor, b: Optional[Tensor], op: int) -> Tensor:
-    return ReduceSum.apply(a, b, op)[0]
+def reduce_sum(a: Tensor, b: Optional[Tensor], op: int, scale: float = 1.0) -> Tensor:
+    """scale * sum_i f(a_i, b_i) as a 0-dim fp32 tensor (the scale -- typically 1/numel -- is applied inside the kernel)."""
+    return ReduceSum.apply(a, b, op, scale)
 
 
 class LatentSums(torch.autograd.Function):

@@ -496,8 +496,11 @@ def test_small_elementwise_and_reductions():
         ga_ref, = torch.autograd.grad(s_ref * 0.37, ar)
         ag = a.to(DEV).requires_grad_(True)
         s = ops.reduce_sum(ag, b.to(DEV) if op == L.RED_ABSDIFF else None, op)
-        assert float(s) == pytest.approx(float(s_ref), rel=1e-5)
+        assert s.dim() == 0 and float(s) == pytest.approx(float(s_ref), rel=1e-5)
         close(torch.autograd.grad(s * 0.37, ag)[0], ga_ref, 1e-6, f"reduce grad {op}")
+        s2 = ops.reduce_sum(ag, b.to(DEV) if op == L.RED_ABSDIFF else None, op, 0.37)  # the scale applied inside the kernels
+        assert float(s2) == pytest.approx(0.37 * float(s_ref), rel=1e-5)
+        close(torch.autograd.grad(s2, ag)[0], ga_ref, 1e-6, f"scaled reduce grad {op}")
     # permuted ([B,C,L] view of an NLC buffer) operands are reduced without a copy and get a permuted gradient
     an = a.permute(0, 2, 1).contiguous().to(DEV).requires_grad_(True)
     s = ops.reduce_sum(an.permute(0, 2, 1), b.permute(0, 2, 1).contiguous().to(DEV).permute(0, 2, 1), L.RED_ABSDIFF)
