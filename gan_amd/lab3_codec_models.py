@@ -148,6 +148,9 @@ class WaveDiscBlock(nn.Module):
         return _conv_train(x_nlc, self.conv, self.geom, x_nlc.dtype, act, self.conv.weight_g, self.conv.weight_v)
 
 
+FUSED_DISC_CHAIN = True  # tests switch this off to compare against the layer-by-layer autograd nodes
+
+
 class SingleScaleWaveDiscriminator(nn.Module):
     """reference lab3_codec_models.py:131-152"""
 
@@ -166,13 +169,22 @@ class SingleScaleWaveDiscriminator(nn.Module):
         self._g_out = ConvGeom("conv", 512, 1, 3, 1, 1, 1)
 
     def forward_nlc(self, x: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
-        feats: List[torch.Tensor] = []
-        h = x
-        for blk in self.blocks:
-            h = blk.run(h, L.ACT_LRELU)
-            feats.append(h)
-        logits = _conv_train(h, self.out, self._g_out, h.dtype, L.ACT_NONE, self.out.weight_g, self.out.weight_v)
-        return logits, feats
+        if not FUSED_DISC_CHAIN:
+            feats: List[torch.Tensor] = []
+            h = x
+            for blk in self.blocks:
+                h = blk.run(h, L.ACT_LRELU)
+                feats.append(h)
+            logits = _conv_train(h, self.out, self._g_out, h.dtype, L.ACT_NONE, self.out.weight_g, self.out.weight_v)
+            return logits, feats
+        # one autograd node for the whole scale (ops.DiscChain): its backward fuses masks and gradient sums across layers
+        convs = [(blk.conv, blk.geom) for blk in self.blocks] + [(self.out, self._g_out)]
+        flat = []
+        for conv, geom in convs:
+            wp_f, wp_d, carrier = ops.PackTrainable.apply(conv.weight_v, conv.weight_g, geom, x.dtype)
+            flat += [wp_f, wp_d, carrier, conv.bias]
+        outs = ops.DiscChain.apply(x, tuple(g for _, g in convs), *flat)
+        return outs[-1], list(outs[:-1])
 
     def forward(self, wav: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         logits, feats = self.forward_nlc(wav.permute(0, 2, 1).contiguous())

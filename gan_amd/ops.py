@@ -507,6 +507,73 @@ class ConvTrain(torch.autograd.Function):
         return gx, None, None, gw, gb, None, None
 
 
+class DiscChain(torch.autograd.Function):
+    """A whole single-scale waveform discriminator (reference lab3_codec_models.py:131-152): n-1 x [conv + bias +
+    LeakyReLU(0.2)] and the logits conv, as ONE autograd node, so that the backward pass can fuse across layers what
+    separate nodes cannot: the data-gradient launch of layer l+1 applies layer l's LeakyReLU mask (and adds the gradient
+    that arrives at feature map l from outside, e.g. feature matching) in its epilogue and so emits the masked gradient
+    layer l needs directly -- no gradient accumulation pass and no mask pass over the feature maps.
+    inputs : x [B, L, C0], geoms, then per layer (forward pack, data-gradient pack, fp32 gradient carrier, bias)
+    outputs: the n-1 feature maps (post-activation, NLC) and the logits."""
+
+    @staticmethod
+    def forward(ctx, x, geoms, *flat):
+        n = len(geoms)
+        assert len(flat) == 4 * n
+        h = x.contiguous()
+        saved_in, outs = [], []
+        for l, g in enumerate(geoms):
+            wp_f, bias = flat[4 * l], flat[4 * l + 3]
+            saved_in.append(h)
+            h = conv_forward(g, h, wp_f, bias, post_act=L.ACT_LRELU if l < n - 1 else L.ACT_NONE)
+            outs.append(h)
+        ctx.geoms = geoms
+        ctx.has_bias = [flat[4 * l + 3] is not None for l in range(n)]
+        ctx.save_for_backward(saved_in[0], *outs[:-1], *[flat[4 * l + 1] for l in range(n)])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        geoms = ctx.geoms
+        n = len(geoms)
+        saved = ctx.saved_tensors
+        ins = list(saved[:n])          # input of layer l: x, y_0 .. y_{n-2}
+        wp_d = list(saved[n:2 * n])
+        grads = [None] * (2 + 4 * n)
+        dtype = ins[0].dtype
+        ga = gouts[n - 1]              # the logits conv has no activation
+        if ga is not None:
+            ga = ga.contiguous().to(dtype)
+        for l in range(n - 1, -1, -1):
+            g_feat = gouts[l - 1] if l > 0 else None
+            if ga is None and g_feat is None:
+                continue
+            if ga is not None:
+                need_w, need_b = ctx.needs_input_grad[2 + 4 * l + 2], ctx.has_bias[l] and ctx.needs_input_grad[2 + 4 * l + 3]
+                if need_w:
+                    if need_b:
+                        gw, gb = conv_wgrad(geoms[l], ga, ins[l], want_bias=True)
+                        grads[2 + 4 * l + 3] = gb
+                    else:
+                        gw = conv_wgrad(geoms[l], ga, ins[l])
+                    grads[2 + 4 * l + 2] = gw.reshape(-1)
+                elif need_b:
+                    grads[2 + 4 * l + 3] = colsum(ga)
+            if l == 0:
+                if ga is not None and ctx.needs_input_grad[0]:
+                    grads[0] = conv_dgrad(geoms[0], ga, wp_d[0], ins[0].shape[1])
+                break
+            # masked gradient of layer l-1:  (dgrad_l(ga) + g_feat) * lrelu'(y_{l-1})
+            y_prev = ins[l]
+            extra = act_bwd(g_feat.contiguous().to(dtype), y_prev, L.DACT_LRELU_FROM_OUT) if g_feat is not None else None
+            if ga is not None:
+                ga = conv_dgrad(geoms[l], ga, wp_d[l], y_prev.shape[1], dact_mode=L.DACT_LRELU_FROM_OUT, dact_src=y_prev, res=extra)
+            else:
+                ga = extra
+        return tuple(grads)
+
+
 def act_fwd(x: Tensor, act: int) -> Tensor:
     y = torch.empty_like(x)
     L.check(L.lib().ga_act_fwd(x.data_ptr(), y.data_ptr(), L.dt(x), x.numel(), act, L.stream()), "ga_act_fwd")

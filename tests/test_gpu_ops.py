@@ -308,6 +308,54 @@ def test_single_channel_mfma_kernels_match_direct(shape):
     close(outs[L.IMPL_AUTO][2], outs[L.IMPL_DIRECT][2], 2e-3, "cin1 db")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_disc_chain_node_matches_layer_by_layer_autograd(precision):
+    """ops.DiscChain (one autograd node per discriminator scale: masks and incoming feature gradients fused into the
+    data-gradient epilogues) against the layer-by-layer ConvTrain nodes: outputs, input gradient, every parameter gradient,
+    for a logits-only loss (D step), a logits + feature loss (G step: gradients arrive at every feature map), a
+    features-only loss, and with D's parameters frozen."""
+    from gan_amd import lab3_codec_models as M
+    torch.manual_seed(77)
+    disc = M.SingleScaleWaveDiscriminator().to(DEV)
+    dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+    x0 = torch.randn(3, 4099, 1, device=DEV).to(dtype)
+    tol = 2e-4 if precision == "fp32" else 2e-2
+
+    def run(fused, mode, freeze):
+        M.FUSED_DISC_CHAIN = fused
+        for prm in disc.parameters():
+            prm.grad = None
+            prm.requires_grad_(not freeze)
+        x = x0.clone().requires_grad_(True)
+        logits, feats = disc.forward_nlc(x)
+        torch.manual_seed(5)
+        loss = 0.0
+        if mode in ("logits", "both"):
+            loss = loss + (logits.float() * torch.randn_like(logits.float())).sum()
+        if mode in ("feats", "both"):
+            for f in feats:
+                loss = loss + (f.float() * torch.randn_like(f.float())).mean() * 50.0
+        loss.backward()
+        outs = [logits.detach().float().cpu()] + [f.detach().float().cpu() for f in feats]
+        grads = [x.grad.float().cpu()] + [prm.grad.float().cpu() for prm in disc.parameters() if prm.grad is not None]
+        return outs, grads
+
+    try:
+        for mode, freeze in (("logits", False), ("both", False), ("feats", False), ("both", True)):
+            o1, g1 = run(True, mode, freeze)
+            o0, g0 = run(False, mode, freeze)
+            want = 1 if freeze else (1 + 18 if mode != "feats" else 1 + 15)  # (features-only: the logits conv gets no gradient)
+            assert len(o1) == len(o0) and len(g1) == len(g0) == want, (mode, freeze, len(g1), len(g0))
+            for a, b in zip(o1, o0):
+                assert torch.equal(a, b), (mode, "forward differs")
+            for i, (a, b) in enumerate(zip(g1, g0)):
+                close(a, b, tol, f"{mode} frozen={freeze} grad {i}")
+    finally:
+        M.FUSED_DISC_CHAIN = True
+        for prm in disc.parameters():
+            prm.requires_grad_(True)
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
