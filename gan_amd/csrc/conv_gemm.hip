@@ -45,7 +45,7 @@ __device__ __forceinline__ void divmod_small(int n, int d, float rcp, int& q, in
 
 // MI: 32-row MFMA tiles per wave along m (2: wave tile 64 x 64, 1: wave tile 32 x 64 for layers with <= 32 output channels)
 template <int MI, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot) {
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
     constexpr int WMR = MI * 32;               // rows (m) per wave
     constexpr int BM = WM * WMR, BN = WN * 64;
     constexpr int NA = (BM * 8 + 255) / 256;   // 16-byte pieces per thread per K-step, A (weights)
@@ -71,10 +71,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const int ks_begin = ksplit > 1 ? (int)((long)nsteps * split / ksplit) : 0;
     const int ks_end = ksplit > 1 ? (int)((long)nsteps * (split + 1) / ksplit) : nsteps;
     int my = 0, rem = wk, phase = 0, bx;
-    const int per_m = nN * p.nphase;
-    if (wk >= per_m) divmod_small(wk, per_m, __builtin_amdgcn_rcpf((float)per_m), my, rem);
-    bx = rem;
-    if (p.nphase > 1) divmod_small(rem, nN, __builtin_amdgcn_rcpf((float)nN), phase, bx);
+    const int mgroup = mgroup_flags & 0xffff;
+    if (mgroup > 1 && p.nphase == 1) {
+        // groups of `mgroup` m-tiles walk the n-tiles together (m fastest inside a group): the workgroups that run side by
+        // side on an XCD then share one x tile in its L2 instead of each streaming a different one
+        const int per_g = mgroup * nN;
+        int gm, r2;
+        divmod_small(wk, per_g, __builtin_amdgcn_rcpf((float)per_g), gm, r2);
+        const int nM_ = (p.M + BM - 1) / BM;
+        const int gcur = min(mgroup, nM_ - gm * mgroup);
+        int q;
+        divmod_small(r2, gcur, __builtin_amdgcn_rcpf((float)gcur), bx, q);
+        my = gm * mgroup + q;
+    } else {
+        const int per_m = nN * p.nphase;
+        if (wk >= per_m) divmod_small(wk, per_m, __builtin_amdgcn_rcpf((float)per_m), my, rem);
+        bx = rem;
+        if (p.nphase > 1) divmod_small(rem, nN, __builtin_amdgcn_rcpf((float)nN), phase, bx);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -114,8 +128,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     int st_dj, st_dc;
     divmod_small(GBK, Cin, __builtin_amdgcn_rcpf((float)Cin), st_dj, st_dc);
     const int st_ddR = st_dj * p.tap_step, st_dkk = st_dj * tapB + st_dc * 2;
-    int st_k = ks_begin * GBK + piece * 8, st_c, st_dR, st_kk;
-    {
+    // K order.  Default: k = (tap, channel), 64 at a time.  With several 64-channel chunks per tap (Cin = 128 .. 1024) the
+    // stages walk the TAPS of one channel chunk first ("tap-fast"): consecutive stages then gather the same x rows shifted
+    // by one tap, so the re-read comes a stage later and hits L2, instead of Cin/64 stages later behind everything the other
+    // workgroups of the XCD have streamed through it meanwhile (PMC: 11-tap layers fetched their input 11 times over).
+    const bool tapfast = !(mgroup_flags & 0x10000) && p.J > 1 && Cin > GBK && Cin % GBK == 0;
+    int st_k, st_c, st_dR, st_kk, st_j = 0;
+    if (tapfast) {
+        int cc0;
+        divmod_small(ks_begin, p.J, __builtin_amdgcn_rcpf((float)p.J), cc0, st_j);
+        st_c = cc0 * GBK + piece * 8;
+        st_k = st_j * Cin + st_c;
+        st_dR = st_j * p.tap_step;
+        st_kk = st_j * tapB + st_c * 2;
+    } else {
+        st_k = ks_begin * GBK + piece * 8;
         int j0;
         divmod_small(st_k, Cin, __builtin_amdgcn_rcpf((float)Cin), j0, st_c);
         st_dR = j0 * p.tap_step;
@@ -147,6 +174,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
                 const bool ok = kin && xitem[i] && R < p.Lin;
                 glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * 4096);
             }
+        }
+        if (tapfast) {
+            st_k += Cin;
+            st_dR += p.tap_step;
+            st_kk += tapB;
+            if (++st_j == p.J) {  // next channel chunk, back to tap 0
+                st_j = 0;
+                st_c += GBK;
+                st_k += GBK - p.J * Cin;
+                st_dR = 0;
+                st_kk += GBK * 2 - p.J * tapB;
+            }
+            return;
         }
         st_k += GBK;
         st_c += st_dc;
@@ -436,6 +476,19 @@ static int gemm_deep_max_blocks() {
     return v;
 }
 
+// m-tiles per group in the tile order (see the kernel); GA_GEMM_MGROUP overrides (tuning aid)
+static int gemm_mgroup() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_MGROUP");
+        v = e ? atoi(e) : 8;
+        if (v < 1) v = 1;
+        const char* t = getenv("GA_GEMM_TAPFAST");  // "0": keep the plain (tap, channel) K order
+        if (t && t[0] == '0') v |= 0x10000;
+    }
+    return v;
+}
+
 template <int MI, int WM, int WN, int NBUF>
 static int launch_gemm(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * 64;
@@ -457,7 +510,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
             return GA_ERR_LAUNCH;
     }
     const int grid = (int)((total + 7) / 8 * 8);
-    kern<<<grid, 256, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot);
+    kern<<<grid, 256, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup());
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
