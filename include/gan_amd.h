@@ -92,6 +92,14 @@ typedef struct ga_conv_params {
  *   dec HF modeling_encodec.py:106 (EncodecConv1d, reflect causal pad :157-176), :193 (EncodecConvTranspose1d,
  *       right trim :206-233), called through lab3_codec_bridge.py:143 */
 int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t stream);
+/* Kernel selection (bf16, impl AUTO / MFMA), all the same arithmetic:
+ *   - M <= 64 and J*Cin <= 192: conv_stream_kernel (operands global -> MFMA registers; fuses pre_act ELU).  It also serves
+ *     Cin == 1 (D blocks.0 on the waveform) when the caller passes a ZERO-PADDED copy of x in which every 8-sample window
+ *     the problem touches is in range: pad_mode 0, tap_step 1, off0 >= 0 and (Lout-1)*in_stride + off0 + 16*ceil(J/16)
+ *     <= Lin (gan_amd/ops.py pads once per waveform); otherwise Cin == 1 runs the vector-ALU kernels of thin.hip;
+ *   - otherwise Cin % 8 == 0, M >= 16, no pre_act: conv_gemm_kernel (gathered GEMM through LDS); a layer with pre_act there
+ *     is given act(x) materialised by ga_act_fwd;
+ *   - M <= 4 (logits / waveform convs): conv_fewout kernels.  fp32 problems run conv_direct (exact fp32 FMA chains). */
 /* split-K helpers (no counterpart in the reference: a scheduling detail of the same convolutions).
  * ga_conv_suggest_ksplit: the split ga_conv would profit from for this problem (1 = do not split);
  * ga_conv_finish: y = epi(ws) over the rows the problem covers, after a ga_conv launch with ksplit > 1. */
@@ -128,6 +136,8 @@ typedef struct ga_wgrad_params {
                            the reduction range then write their partial tiles as plain stores to slabs that one more
                            kernel adds into dw, instead of fp32 atomics on dw; NULL = atomics */
 } ga_wgrad_params;
+/* bf16 kernels: wgrad_gemm_kernel (Cin % 8 == 0); Cin == 1 with a zero-padded x (in_stride 1, tap_step 1, off0 >= 0, J <= 15
+ * with dbias, every window in range as for ga_conv): wgrad_cin1_mfma_kernel, which also fills dbias; M == 1: wgrad_m1 kernels. */
 int ga_wgrad(const ga_wgrad_params* h_params, int dtype, int impl, ga_stream_t stream);
 /* floats of workspace ga_wgrad can use for this problem (0: the kernel it would pick has no slab path) */
 size_t ga_wgrad_workspace_elems(const ga_wgrad_params* h_params, int dtype, int impl);
