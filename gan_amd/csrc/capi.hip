@@ -103,7 +103,11 @@ int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_wgrad_gemm_supported(p);
     int rc;
     if (impl == GA_IMPL_MFMA_WINDOW) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
-    else if ((impl == GA_IMPL_MFMA || impl == GA_IMPL_AUTO) && can_gemm) rc = ga_wgrad_gemm_impl(p, s);
+    else if ((impl == GA_IMPL_MFMA || impl == GA_IMPL_AUTO) && can_gemm) {
+        rc = ga_wgrad_gemm_impl(p, s);
+        // without slabs the kernel has produced the bias gradient itself (a constant-one column of the gathered operand)
+        if (rc == GA_OK && p.dbias && !(p.ws && p.M > 64)) return (p.g_stride != 1 || p.g_phase != 0 || p.LgTot != p.Lout) ? GA_ERR_ARG : GA_OK;
+    }
     else if (impl == GA_IMPL_MFMA) rc = can_mfma ? ga_wgrad_mfma_impl(p, s) : GA_ERR_ARG;
     else if (impl == GA_IMPL_AUTO && can_mfma) rc = ga_wgrad_mfma_impl(p, s);
     else if (impl != GA_IMPL_AUTO && impl != GA_IMPL_DIRECT) rc = GA_ERR_ARG;

@@ -41,6 +41,10 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// Bias gradient from the same MFMAs: db[m] = sum_n G[n][m] * 1 is column k = Ktot of dW when the gathered operand gets a
+// constant-one column there.  The 16-byte piece at k = Ktot reads this page (bf16 1.0 followed by seven zeros).
+static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0x00003F80u, 0u, 0u, 0u};
+
 #define WGG_RK 64    // reduction rows per step
 #define WGG_TILE (WGG_RK * 256)  // bytes of one operand tile
 
@@ -70,6 +74,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
     const bool a_ok = am < p.M;
     const int bk = kbase + lpiece * 8;
     const bool b_ok = bk < Ktot;
+    const bool b_one = p.dbias && bk == Ktot;  // the bias column (fused only without slabs: see ga_wgrad_gemm_impl)
+    const uintptr_t one = (uintptr_t)wgg_one_page;
+    const int Kcols = Ktot + (p.dbias ? 1 : 0);
     const int bj = b_ok ? bk / Cin : 0;
     const int bc = b_ok ? bk - bj * Cin : 0;
     const int bdR = bj * p.tap_step + p.off0;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
             wg_glds16(wg_sel(n_ok && a_ok, asrc, zero), ab + i * 4096);
             const int R = rt[i] * S + bdR;
             const uintptr_t bsrc = (uintptr_t)(x + ((size_t)rb[i] * p.Lin + R) * Cin + bc);
-            wg_glds16(wg_sel(n_ok && b_ok && R >= 0 && R < p.Lin, bsrc, zero), bb + i * 4096);
+            wg_glds16(wg_sel(b_one, one, wg_sel(n_ok && b_ok && R >= 0 && R < p.Lin, bsrc, zero)), bb + i * 4096);
             // advance this row by one reduction step
             rt[i] += WGG_RK;
             while (rt[i] >= p.Lout) { rt[i] -= p.Lout; ++rb[i]; }
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
         offA[i] = ((((ecolA[i] >> 3) ^ (q << 2)) << 4) | ((ecolA[i] & 7) << 1)) + (8 * h + q) * 256;
         offB[i] = ((((ecolB[i] >> 3) ^ (q << 2)) << 4) | ((ecolB[i] & 7) << 1)) + (8 * h + q) * 256;
     }
-    const bool wave_active = (mbase + wme * 64) < p.M && (kbase + wn * 64) < Ktot;
+    const bool wave_active = (mbase + wme * 64) < p.M && (kbase + wn * 64) < Kcols;
 
     if (s_begin < s_end) issue(0);
     for (int st = s_begin; st < s_end; ++st) {
@@ -156,7 +163,17 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int k = kbase + wn * 64 + ni * 32 + r;
-        if (k >= Ktot) continue;
+        if (k >= Kcols) continue;
+        if (k == Ktot) {  // bias column
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = mbase + wme * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (m < p.M) atomicAdd(&p.dbias[m], acc[mi][ni][i]);
+                }
+            continue;
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 }
 
 static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles) {
-    const int Ktot = p.J * p.Cin;
+    const int Ktot = p.J * p.Cin + (p.dbias ? 8 : 0);  // (+ one 16-byte piece for the bias column)
     const long Ntot = (long)p.B * p.Lout;
     const int mtiles = (p.M + 127) / 128;
     ktiles = (Ktot + 127) / 128;
@@ -211,7 +228,9 @@ size_t ga_wgrad_gemm_workspace_elems(const WgradParams& p) {
     if (!ga_wgrad_gemm_supported(p) || p.M <= 64) return 0;  // (M <= 64: two waves share an output sub-tile: atomics only)
     long base, splits, nsteps;
     int sps, ktiles;
-    wgg_plan(p, base, splits, sps, nsteps, ktiles);
+    WgradParams q = p;
+    q.dbias = nullptr;  // (slab mode never fuses the bias column: plan exactly as ga_wgrad_gemm_impl will)
+    wgg_plan(q, base, splits, sps, nsteps, ktiles);
     return (size_t)splits * p.M * p.J * p.Cin;
 }
 
@@ -219,6 +238,7 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
     if (!ga_wgrad_gemm_supported(p_in)) return GA_ERR_ARG;
     WgradParams p = p_in;
     if (p.M <= 64) p.ws = nullptr;
+    if (p.ws) p.dbias = nullptr;  // slab mode reduces dW only: the caller adds the bias gradient (ga_colsum)
     const int Ktot = p.J * p.Cin;
     const long Ntot = (long)p.B * p.Lout;
     long base, splits, nsteps;
