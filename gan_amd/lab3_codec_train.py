@@ -225,8 +225,12 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
                           q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
                           q_real_tgt: Optional[torch.Tensor], q_real_tgt_g: torch.Tensor, global_step: int,
                           noise2: Optional[torch.Tensor] = None, dp=None, prefetcher=None,
-                          next_frozen: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                          next_frozen: Optional[List[torch.Tensor]] = None, style_judge=None,
+                          tgt_genre_idx: Optional[torch.Tensor] = None,
+                          src_genre_idx: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """One iteration of the reference loop body (:404-591).  Returns device scalars (no host sync).
+    style_judge (+ tgt_genre_idx / src_genre_idx, device int64 [B]): the frozen CodecStyleJudge of style_loss_mode
+    "codec_judge_ce" (:480-494); None leaves the style terms at zero.
     prefetcher / next_frozen: see gan_amd/prefetch.py - the frozen latents of the NEXT iteration ([q_src, q_real_tgt (if
     that iteration takes a D step), q_real_tgt_g]) are decoded on a side stream while this iteration runs."""
     device = q_src.device
@@ -307,9 +311,17 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     zero = torch.zeros((), device=device)
     loss_content = zero
     loss_style = zero
+    loss_style_embed = zero
     loss_style_push = zero
     loss_ms = zero
     w = stage_cfg.weights
+    if style_judge is not None and str(stage_cfg.style_loss_mode).strip().lower() == "codec_judge_ce":
+        from .lab3_codec_judge import codec_judge_style_terms
+        if tgt_genre_idx is None or src_genre_idx is None:
+            raise ValueError("style_judge needs tgt_genre_idx and src_genre_idx")
+        loss_style, loss_style_embed, loss_style_push = codec_judge_style_terms(
+            style_judge, q_hat, z_style_tgt, tgt_genre_idx, src_genre_idx, float(stage_cfg.style_embed_align_weight),
+            float(stage_cfg.style_push_margin), stage1=str(stage_cfg.stage_name) == "stage1")
     if float(w.mode_seeking) > 0.0:
         if noise2 is None:
             noise2 = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
@@ -323,6 +335,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     loss_g = (float(w.adv) * loss_adv + float(w.feature_match) * loss_fm + float(w.latent_l1) * loss_lat_l1
               + float(w.latent_continuity) * loss_lat_cont + float(w.mrstft) * loss_mrstft
               + float(w.mode_seeking) * loss_ms + float(w.delta_budget) * loss_delta_budget)
+    if style_judge is not None:
+        loss_g = loss_g + float(w.style) * loss_style + float(w.style_push) * loss_style_push
     opt_g.zero_grad(set_to_none=True)
     opt_g.max_grad_norm = float(stage_cfg.g_grad_clip_norm)
     _backward_and_reduce(loss_g, opt_g, dp)
@@ -331,7 +345,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     out.update(loss_g=loss_g.detach(), loss_adv=loss_adv.detach(), loss_fm=loss_fm.detach(),
                loss_lat_l1=loss_lat_l1.detach(), loss_lat_cont=loss_lat_cont.detach(), loss_mrstft=loss_mrstft.detach(),
                loss_delta_budget=loss_delta_budget.detach(), loss_ms=loss_ms.detach(), loss_content=loss_content,
-               loss_style=loss_style, loss_style_push=loss_style_push, g_grad_norm=opt_g.last_grad_norm,
+               loss_style=loss_style.detach(), loss_style_embed=loss_style_embed.detach(),
+               loss_style_push=loss_style_push.detach(), g_grad_norm=opt_g.last_grad_norm,
                q_hat=q_hat.detach(), x_hat=x_hat.detach())
     return out
 
@@ -345,11 +360,22 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
     """reference :267-648.  Same arguments and the same 19-key history rows.  Losses are accumulated on the device and
     read back once per epoch (the reference syncs 12 scalars per iteration, :593-604)."""
     w = stage_cfg.weights
-    if lab1_encoder is not None or style_judge is not None or lab1_probe is not None or mert_probe is not None:
-        raise NotImplementedError("content / style terms (Lab1 encoder, style judge, probes) are outside the accelerated "
+    if lab1_encoder is not None or lab1_probe is not None or mert_probe is not None:
+        raise NotImplementedError("content / probe terms (Lab1 encoder, Lab1 / MERT probes) are outside the accelerated "
                                   "path; pass None (SURVEY.md section 8(f) next-1)")
-    if float(w.content) > 0.0 or float(w.style) > 0.0 or float(w.style_push) > 0.0:
-        warnings.warn("content / style / style_push weights are ignored: those terms are not part of this path", stacklevel=2)
+    style_mode = str(stage_cfg.style_loss_mode).strip().lower()
+    use_judge = style_judge is not None and style_mode == "codec_judge_ce"
+    if style_judge is not None:
+        from .lab3_codec_judge import CodecStyleJudge
+        if not isinstance(style_judge, CodecStyleJudge):
+            raise TypeError("style_judge must be a gan_amd.lab3_codec_judge.CodecStyleJudge (load the reference judge's "
+                            "state_dict into one: the keys are the same)")
+        style_judge.eval()  # frozen, as reference :289-292
+        for p in style_judge.parameters():
+            p.requires_grad = False
+    if float(w.content) > 0.0 or ((float(w.style) > 0.0 or float(w.style_push) > 0.0) and not use_judge):
+        warnings.warn("content weight (and style weights without a codec_judge_ce style judge) are ignored: those terms "
+                      "are not part of this path", stacklevel=2)
     generator.train()
     discriminator.train()
     style_centroid_bank = style_centroid_bank.to(device)
@@ -367,7 +393,7 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
     # off by default: on MI355X / ROCm 7.2 the side-stream chain was measured not to overlap with the main stream
     prefetcher = FrozenDecodePrefetcher(codec) if (prefetch and device.type == "cuda") else None
     keys = ("loss_g", "loss_d", "loss_adv", "loss_fm", "loss_lat_l1", "loss_lat_cont", "loss_content", "loss_style",
-            "loss_style_push", "loss_delta_budget", "loss_mrstft", "loss_ms")
+            "loss_style_embed", "loss_style_push", "loss_delta_budget", "loss_mrstft", "loss_ms")
     for epoch in range(start_epoch + 1, int(stage_cfg.epochs) + 1):
         alpha = float(stage_cfg.cond_alpha_start)
         if int(stage_cfg.epochs) > 1:
@@ -399,8 +425,10 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             take_d = (step % max(1, int(stage_cfg.d_step_period))) == 0
             q_real_tgt = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float() if take_d else None
             q_real_tgt_g = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float()
+            tgt_dev = tgt_genre_idx.to(device, non_blocking=True) if use_judge else None
+            src_dev = src_genre_idx.to(device, non_blocking=True) if use_judge else None
             return dict(q_src=q_src, zc_src=zc_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, q_real_tgt=q_real_tgt,
-                        q_real_tgt_g=q_real_tgt_g, step=step)
+                        q_real_tgt_g=q_real_tgt_g, step=step, tgt_genre_idx=tgt_dev, src_genre_idx=src_dev)
 
         def frozen_of(item):
             return [item["q_src"]] + ([item["q_real_tgt"]] if item["take_d"] else []) + [item["q_real_tgt_g"]]
@@ -422,7 +450,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             take_d = cur["take_d"]
             res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, cur["q_src"], cur["zc_src"],
                                         cur["z_style_tgt"], cur["noise"], cur["q_real_tgt"], cur["q_real_tgt_g"], global_step,
-                                        dp=dp, prefetcher=prefetcher, next_frozen=frozen_of(ahead) if ahead is not None else None)
+                                        dp=dp, prefetcher=prefetcher, next_frozen=frozen_of(ahead) if ahead is not None else None,
+                                        style_judge=style_judge if use_judge else None,
+                                        tgt_genre_idx=cur["tgt_genre_idx"], src_genre_idx=cur["src_genre_idx"])
             cur = ahead
             if take_d:
                 d_steps_taken += 1
@@ -438,7 +468,8 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             "loss_d": (host["loss_d"] / max(1, d_steps_taken)) if d_steps_taken > 0 else 0.0,
             "loss_adv": host["loss_adv"] / n, "loss_feature_match": host["loss_fm"] / n,
             "loss_latent_l1": host["loss_lat_l1"] / n, "loss_continuity": host["loss_lat_cont"] / n,
-            "loss_content": host["loss_content"] / n, "loss_style": host["loss_style"] / n, "loss_style_embed": 0.0,
+            "loss_content": host["loss_content"] / n, "loss_style": host["loss_style"] / n,
+            "loss_style_embed": host["loss_style_embed"] / n,
             "loss_style_push": host["loss_style_push"] / n, "loss_delta_budget": host["loss_delta_budget"] / n,
             "loss_mrstft": host["loss_mrstft"] / n, "loss_mode_seeking": host["loss_ms"] / n,
             "d_steps_taken": int(d_steps_taken), "d_steps_skipped": int(d_steps_skipped),

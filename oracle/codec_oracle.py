@@ -9,6 +9,8 @@ It is an independent restatement, in stock torch CPU fp32 ops, of the reference 
   * discriminator D ........ lab3_codec_models.py:122-168
   * hinge / FM losses ...... lab3_codec_models.py:171-215
   * MR-STFT loss ........... /root/reference/lab 3/src/lab3_codec_train.py:148-176
+  * codec style judge ...... /root/reference/lab 3/src/lab3_codec_judge.py:83-145 and the style terms of the G step,
+    lab3_codec_train.py:480-494 (pinned by tests/golden/judge_golden.npz, made by tests/golden/make_golden_judge.py)
   * training iteration ..... lab3_codec_train.py:404-591 (north-star loss subset), clip + AdamW :302-311,446-448,589-591
   * frozen SEANet decoder .. third-party `transformers` 5.15.0 (unpinned in lab 3/requirements.txt:6),
     models/encodec/modeling_encodec.py:76-176 (EncodecConv1d), :179-233 (EncodecConvTranspose1d),
@@ -295,6 +297,35 @@ def decoder_forward(sd: SD, q: Tensor, fast_lstm: bool = True, collect: Optional
         h = rec(_causal_conv(sd, p + "shortcut.conv.", h) + t); idx += 1
     h = rec(F.elu(h)); idx += 1
     return rec(_causal_conv(sd, f"layers.{idx}.conv.", h))
+
+
+# ------------------------------------------------------------------------------------------------
+# CodecStyleJudge (lab3_codec_judge.py:83-145) and the codec_judge_ce style terms (lab3_codec_train.py:480-494)
+def style_judge_embed(sd: SD, q_emb: Tensor) -> Tensor:
+    """net = 3 x [Conv1d -> GroupNorm(8) -> SiLU] (k5 p2, k3 p1, k3 p1), mean over time, proj, L2-normalise (:131-135)."""
+    h = q_emb
+    for ci, gi, pad in ((0, 1, 2), (3, 4, 1), (6, 7, 1)):
+        h = F.conv1d(h, sd[f"net.{ci}.weight"], sd[f"net.{ci}.bias"], padding=pad)
+        h = F.silu(F.group_norm(h, 8, sd[f"net.{gi}.weight"], sd[f"net.{gi}.bias"], eps=1e-5))
+    e = F.linear(h.mean(dim=-1), sd["proj.weight"], sd["proj.bias"])
+    return F.normalize(e, dim=-1)
+
+
+def style_judge_terms(sd: SD, q_hat: Tensor, z_style_tgt: Tensor, tgt_genre_idx: Tensor, src_genre_idx: Tensor,
+                      embed_align_weight: float, push_margin: float, stage1: bool = False):
+    """(loss_style, loss_style_embed, loss_style_push, emb, logits) as the reference's G step forms them (:480-494)."""
+    emb = style_judge_embed(sd, q_hat)
+    logits = F.linear(emb, sd["head.weight"], sd["head.bias"])
+    loss_style = F.cross_entropy(logits, tgt_genre_idx)
+    loss_embed = torch.zeros(())
+    if embed_align_weight > 0.0 and z_style_tgt.shape[1] == emb.shape[1]:
+        loss_embed = (1.0 - F.cosine_similarity(emb, F.normalize(z_style_tgt, dim=-1), dim=-1)).mean()
+        loss_style = loss_style + embed_align_weight * loss_embed
+    loss_push = torch.zeros(())
+    if not stage1:
+        p_src = torch.softmax(logits, dim=1).gather(1, src_genre_idx.view(-1, 1)).squeeze(1)
+        loss_push = F.relu(p_src - push_margin).mean()
+    return loss_style, loss_embed, loss_push, emb, logits
 
 
 # ------------------------------------------------------------------------------------------------

@@ -84,3 +84,16 @@ def decoder_shapes(hidden_size=128, num_filters=32, ratios=(8, 5, 4, 2), kernel_
     idx += 1  # ELU
     conv(f"layers.{idx}.", 1, num_filters, last_kernel_size)
     return s
+
+
+def style_judge_shapes(in_channels=128, n_genres=10, hidden=256, emb_dim=128) -> Dict[str, Tuple[int, ...]]:
+    """CodecStyleJudge without a source head (lab3_codec_judge.py:92-113): net.{0,3,6} Conv1d, net.{1,4,7} GroupNorm."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    for slot, (ci, k) in zip((0, 3, 6), ((in_channels, 5), (hidden, 3), (hidden, 3))):
+        s[f"net.{slot}.weight"] = (hidden, ci, k)
+        s[f"net.{slot}.bias"] = (hidden,)
+        s[f"net.{slot + 1}.weight"] = (hidden,)
+        s[f"net.{slot + 1}.bias"] = (hidden,)
+    s["proj.weight"], s["proj.bias"] = (emb_dim, hidden), (emb_dim,)
+    s["head.weight"], s["head.bias"] = (n_genres, emb_dim), (n_genres,)
+    return s
