@@ -476,6 +476,17 @@ static int gemm_deep_max_blocks() {
     return v;
 }
 
+// grids of at most this many 128x128 workgroups use 64x128 tiles instead; GA_GEMM_HALF_MAX overrides (tuning aid)
+static int gemm_half_max_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_HALF_MAX");
+        v = e ? atoi(e) : 128;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+
 // m-tiles per group in the tile order (see the kernel); GA_GEMM_MGROUP overrides (tuning aid)
 static int gemm_mgroup() {
     static int v = -1;
@@ -527,6 +538,11 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
     // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
     const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase * (p.ksplit > 1 ? p.ksplit : 1);
+    // few 128x128 tiles (short sequences: the generator's and the judge's convs): 64x128 tiles double the workgroups
+    if (blocks <= gemm_half_max_blocks() && !gemm_nbuf_override()) {
+        if (2 * blocks <= gemm_deep_max_blocks() && ksteps >= 6) return launch_gemm<1, 2, 2, 4>(p, s);
+        return launch_gemm<1, 2, 2, 2>(p, s);
+    }
     int nbuf = gemm_nbuf_override();
     if (!nbuf) nbuf = blocks >= 600 ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);

@@ -186,6 +186,18 @@ class SingleScaleWaveDiscriminator(nn.Module):
         outs = ops.DiscChain.apply(x, tuple(g for _, g in convs), *flat)
         return outs[-1], list(outs[:-1])
 
+    def forward_real_fake_nlc(self, x_real: torch.Tensor, x_fake: torch.Tensor):
+        """G-step pair of passes as one (ops.DiscChainSplit): ((logits, feats) of x_real without gradient, the same of x_fake)."""
+        convs = [(blk.conv, blk.geom) for blk in self.blocks] + [(self.out, self._g_out)]
+        flat = []
+        with torch.no_grad():
+            for conv, geom in convs:
+                wp_f, wp_d, _ = ops.PackTrainable.apply(conv.weight_v, conv.weight_g, geom, x_fake.dtype)
+                flat += [wp_f, wp_d, conv.bias]
+        outs = ops.DiscChainSplit.apply(x_real, x_fake, tuple(g for _, g in convs), *flat)
+        n = len(convs)
+        return (outs[n - 1], list(outs[:n - 1])), (outs[2 * n - 1], list(outs[n:2 * n - 1]))
+
     def forward(self, wav: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         logits, feats = self.forward_nlc(wav.permute(0, 2, 1).contiguous())
         return logits.permute(0, 2, 1), [f.permute(0, 2, 1) for f in feats]
@@ -213,6 +225,31 @@ class MultiScaleWaveDiscriminator(nn.Module):
             logits, feats = d.forward_nlc(x.unsqueeze(-1))
             outs.append((logits.permute(0, 2, 1), [f.permute(0, 2, 1) for f in feats]))
         return outs
+
+    def forward_real_fake(self, wav_real: torch.Tensor, wav_fake: torch.Tensor):
+        """(D(wav_real) without gradient, D(wav_fake) with gradient to wav_fake only) for FROZEN discriminator weights --
+        the generator step's two passes (reference lab3_codec_train.py:455-462) run as one pass over the joined batch."""
+        L.require_cuda(wav_real, wav_fake)
+        if any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("forward_real_fake needs the discriminator's parameters frozen (requires_grad False)")
+        dtype = _act_dtype(self.precision)
+        for w in (wav_real, wav_fake):
+            if w.dim() != 3 or w.shape[1] != 1:
+                raise ValueError(f"expected wav [B, 1, S], got {tuple(w.shape)}")
+        if wav_real.shape[2] != wav_fake.shape[2]:
+            raise ValueError("real and fake waveforms differ in length")
+        xr = wav_real.detach()[:, 0, :].to(dtype)
+        xf = wav_fake[:, 0, :].to(dtype)
+        real_outs, fake_outs = [], []
+        for i, d in enumerate(self.discs):
+            if i > 0:
+                with torch.no_grad():
+                    xr = ops.AvgPool4s2.apply(xr)
+                xf = ops.AvgPool4s2.apply(xf)
+            (lr, fr), (lf, ff) = d.forward_real_fake_nlc(xr.unsqueeze(-1), xf.unsqueeze(-1))
+            real_outs.append((lr.permute(0, 2, 1), [f.permute(0, 2, 1) for f in fr]))
+            fake_outs.append((lf.permute(0, 2, 1), [f.permute(0, 2, 1) for f in ff]))
+        return real_outs, fake_outs
 
 
 # ------------------------------------------------------------------------------------------------

@@ -288,8 +288,6 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         out["loss_d"] = loss_d_total
         out["d_grad_norm"] = opt_d.last_grad_norm
 
-    with torch.no_grad():
-        real_outs_g = discriminator(x_real_g)
     # D's own gradients from the G step are discarded by the reference (zero_grad(set_to_none) at :444 before they
     # are ever used), so the fake pass runs with D's parameters frozen: no D weight-gradient kernels are launched.
     d_params = [p for p in discriminator.parameters()]
@@ -297,7 +295,13 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     for p in d_params:
         p.requires_grad_(False)
     try:
-        fake_outs = discriminator(x_hat)
+        if hasattr(discriminator, "forward_real_fake"):
+            # D(real) under no_grad and D(fake) (:455-462) as one pass over the joined batch
+            real_outs_g, fake_outs = discriminator.forward_real_fake(x_real_g, x_hat)
+        else:
+            with torch.no_grad():
+                real_outs_g = discriminator(x_real_g)
+            fake_outs = discriminator(x_hat)
     finally:
         for p, r in zip(d_params, saved):
             p.requires_grad_(r)

@@ -574,6 +574,64 @@ class DiscChain(torch.autograd.Function):
         return tuple(grads)
 
 
+class DiscChainSplit(torch.autograd.Function):
+    """The generator step's form of DiscChain (reference lab3_codec_train.py:455-462: D(real) under no_grad, then D(fake)
+    whose gradient reaches only the generator).  D's weights are frozen there and D acts on every batch item independently,
+    so both passes run as ONE pass over [real ; fake]: twice the GEMM N per launch, half the launches.  The backward pass
+    runs on the fake items only (contiguous tail slices of the saved feature maps, batch is the outermost axis).
+    inputs : x_real [B0, L, C0] (no gradient), x_fake [B1, L, C0], geoms, then per layer (forward pack, data-gradient
+             pack, bias), all without gradient
+    outputs: n real-half tensors (features then logits; non-differentiable), then the n fake-half tensors."""
+
+    @staticmethod
+    def forward(ctx, x_real, x_fake, geoms, *flat):
+        n = len(geoms)
+        assert len(flat) == 3 * n
+        b0 = int(x_real.shape[0])
+        h = torch.cat([x_real, x_fake], dim=0)
+        outs = []
+        for l, g in enumerate(geoms):
+            h = conv_forward(g, h, flat[3 * l], flat[3 * l + 2], post_act=L.ACT_LRELU if l < n - 1 else L.ACT_NONE)
+            outs.append(h)
+        ctx.geoms, ctx.b0, ctx.len0 = geoms, b0, int(x_fake.shape[1])
+        ctx.save_for_backward(*outs[:-1], *[flat[3 * l + 1] for l in range(n)])
+        ctx.set_materialize_grads(False)
+        real = tuple(o[:b0] for o in outs)
+        ctx.mark_non_differentiable(*real)
+        return real + tuple(o[b0:] for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        geoms, b0 = ctx.geoms, ctx.b0
+        n = len(geoms)
+        saved = ctx.saved_tensors
+        feats = saved[:n - 1]
+        wp_d = saved[n - 1:]
+        gouts = gouts[n:]
+        grads = [None] * (3 + 3 * n)
+        if any(ctx.needs_input_grad[3:]):
+            raise RuntimeError("DiscChainSplit is for frozen discriminator weights")
+        dtype = wp_d[0].dtype
+        ga = gouts[n - 1]
+        if ga is not None:
+            ga = ga.contiguous().to(dtype)
+        for l in range(n - 1, -1, -1):
+            g_feat = gouts[l - 1] if l > 0 else None
+            if ga is None and g_feat is None:
+                continue
+            if l == 0:
+                if ga is not None and ctx.needs_input_grad[1]:
+                    grads[1] = conv_dgrad(geoms[0], ga, wp_d[0], ctx.len0)
+                break
+            y_prev = feats[l - 1][b0:]
+            extra = act_bwd(g_feat.contiguous().to(dtype), y_prev, L.DACT_LRELU_FROM_OUT) if g_feat is not None else None
+            if ga is not None:
+                ga = conv_dgrad(geoms[l], ga, wp_d[l], y_prev.shape[1], dact_mode=L.DACT_LRELU_FROM_OUT, dact_src=y_prev, res=extra)
+            else:
+                ga = extra
+        return tuple(grads)
+
+
 def act_fwd(x: Tensor, act: int) -> Tensor:
     y = torch.empty_like(x)
     L.check(L.lib().ga_act_fwd(x.data_ptr(), y.data_ptr(), L.dt(x), x.numel(), act, L.stream()), "ga_act_fwd")

@@ -356,6 +356,52 @@ def test_disc_chain_node_matches_layer_by_layer_autograd(precision):
             prm.requires_grad_(True)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_joined_real_fake_pass_matches_two_passes(precision):
+    """MultiScaleWaveDiscriminator.forward_real_fake (the G step's D(real) under no_grad + D(fake) as ONE pass over the joined
+    batch, ops.DiscChainSplit) against the two separate passes: every logit / feature map of both halves, and the gradient
+    that reaches the fake waveform from a hinge-like + feature-matching-like loss.  Unequal halves and an odd length."""
+    from gan_amd import lab3_codec_models as M
+    torch.manual_seed(78)
+    D = M.MultiScaleWaveDiscriminator(3, precision=precision).to(DEV)
+    for prm in D.parameters():
+        prm.requires_grad_(False)
+    xr = torch.randn(2, 1, 6007, device=DEV)
+    xf0 = torch.randn(3, 1, 6007, device=DEV)
+    tol = 2e-4 if precision == "fp32" else 2e-2
+
+    def loss_of(real_outs, fake_outs):
+        torch.manual_seed(6)
+        loss = 0.0
+        for (lr, fr), (lf, ff) in zip(real_outs, fake_outs):
+            loss = loss - lf.float().mean()
+            for a, b in zip(fr, ff):
+                loss = loss + (b.float() - a.float().mean(dim=0, keepdim=True)).abs().mean()
+        return loss
+
+    xf = xf0.clone().requires_grad_(True)
+    with torch.no_grad():
+        r_ref = D(xr)
+    f_ref = D(xf)
+    loss_of(r_ref, f_ref).backward()
+    g_ref = xf.grad.clone()
+    xf2 = xf0.clone().requires_grad_(True)
+    r_new, f_new = D.forward_real_fake(xr, xf2)
+    loss_of(r_new, f_new).backward()
+    for (lr, fr), (lr2, fr2) in zip(r_ref + f_ref, r_new + f_new):
+        assert lr.shape == lr2.shape
+        close(lr2.float().cpu(), lr.float().cpu(), tol, "logits")
+        for a, b in zip(fr, fr2):
+            assert a.shape == b.shape
+            close(b.float().cpu(), a.float().cpu(), tol, "feature")
+    assert all(not t.requires_grad for lg, fs in r_new for t in [lg] + fs)
+    close(xf2.grad.cpu(), g_ref.cpu(), tol, "fake waveform gradient")
+    for prm in D.parameters():
+        prm.requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        D.forward_real_fake(xr, xf0)
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
