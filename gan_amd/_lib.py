@@ -39,6 +39,17 @@ class ConvParams(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    """ga_pack_item (include/gan_amd.h)"""
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("scale", C.c_void_p), ("norm", C.c_void_p), ("wp_f", C.c_void_p),
+                ("wp_d", C.c_void_p), ("D0", C.c_int), ("D1", C.c_int), ("K", C.c_int), ("S", C.c_int), ("P", C.c_int),
+                ("mode_f", C.c_int), ("mode_d", C.c_int), ("reserved", C.c_int)]
+
+
+PACK_MULTI_MAX = 24
+PACK_CONV_DGRAD_STRIDED = 2
+
+
 class WgradParams(C.Structure):
     _fields_ = [
         ("g", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
@@ -68,6 +79,7 @@ _SIGNATURES = {
     "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_pack_multi": [_P, _I, _I, _P],
     "ga_unpack_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_wn_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "ga_gn_stats": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P],

@@ -169,6 +169,148 @@ static bool launch_pack_tiled(const float* src, const float* scale, T* dst, floa
     return true;
 }
 
+// ---- every layer of a module in two launches (ga_pack_multi) -------------------------------------------------------
+// A training step repacks ~40 weight tensors (two layouts each, plus the weight-norm scale): ~100 launches, most of them
+// at the launch floor.  Here one launch computes every weight-norm row scale and one launch writes both packs of every
+// layer; a workgroup finds its (layer, layout, tile) from a prefix table in the kernel arguments.
+struct PackMultiArgs {
+    ga_pack_item it[GA_PACK_MULTI_MAX];
+    int first[2 * GA_PACK_MULTI_MAX + 1];  // first workgroup of (layer, layout) in the pack grid
+    int row0[GA_PACK_MULTI_MAX + 1];       // first workgroup (= weight row) of a layer in the scale grid
+    int n;
+};
+
+// 0: plain (4096 elements per workgroup), 1: FAST0 tiles, 2: one-s0 row tiles -- the choice launch_pack_tiled makes
+__host__ __device__ static inline int pack_kind(int mode, int D0, int D1, int K) {
+    const size_t DK = (size_t)D1 * K;
+    if (D0 * DK < 16384) return 0;
+    if (mode == GA_PACK_CONV_DGRAD_S1 || mode == GA_PACK_CONV_DGRAD_STRIDED || mode == GA_PACK_CONVT_FWD) return 1;
+    return K > 65 ? 0 : 2;
+}
+
+static inline long pack_blocks(int mode, int D0, int D1, int K) {
+    const size_t DK = (size_t)D1 * K;
+    switch (pack_kind(mode, D0, D1, K)) {
+        case 1: return (long)((D0 + 63) / 64) * (long)((DK + 63) / 64);
+        case 2: return (long)D0 * ((D1 + 63) / 64);
+        default: return (long)((D0 * DK + 4095) / 4096);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_one_block(float* tile, int lb, const float* __restrict__ src, const float* __restrict__ scale,
+                                               T* __restrict__ dst, int mode, int D0, int D1, int K, int S, int P) {
+    const int tid = threadIdx.x;
+    const size_t DK = (size_t)D1 * K;
+    const int kind = pack_kind(mode, D0, D1, K);
+    if (kind == 1) {
+        const int nbx = (D0 + 63) / 64;
+        const int s0b = (lb % nbx) * 64;
+        const size_t eb = (size_t)(lb / nbx) * 64;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int sl = idx >> 6, el = idx & 63;
+            const int s0 = s0b + sl;
+            const size_t e = eb + el;
+            if (s0 < D0 && e < DK) tile[sl * 65 + el] = src[(size_t)s0 * DK + e] * (scale ? scale[s0] : 1.f);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int el = idx >> 6, sl = idx & 63;
+            const int s0 = s0b + sl;
+            const size_t e = eb + el;
+            if (s0 < D0 && e < DK) dst[pack_index(mode, s0, (int)(e / K), (int)(e % K), D0, D1, K, S, P)] = (T)tile[sl * 65 + el];
+        }
+    } else if (kind == 2) {
+        const int s0 = lb % D0;
+        const int s1b = (lb / D0) * 64;
+        const int ns1 = min(64, D1 - s1b);
+        const int ne = ns1 * K;
+        const size_t base = ((size_t)s0 * D1 + s1b) * K;
+        const float sc = scale ? scale[s0] : 1.f;
+        for (int idx = tid; idx < ne; idx += 256) tile[idx] = src[base + idx] * sc;
+        __syncthreads();
+        for (int idx = tid; idx < 64 * K; idx += 256) {
+            const int k = idx >> 6, s1l = idx & 63;
+            if (s1l < ns1) dst[pack_index(mode, s0, s1b + s1l, k, D0, D1, K, S, P)] = (T)tile[s1l * K + k];
+        }
+    } else {
+        const size_t n = (size_t)D0 * DK;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const size_t i = (size_t)lb * 4096 + idx;
+            if (i < n) {
+                const int k = (int)(i % K);
+                const int s1 = (int)((i / K) % D1);
+                const int s0 = (int)(i / DK);
+                dst[pack_index(mode, s0, s1, k, D0, D1, K, S, P)] = (T)(src[i] * (scale ? scale[s0] : 1.f));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_scale_multi_kernel(const PackMultiArgs a) {
+    __shared__ float red[16];
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.row0[l + 1]) ++l;
+    const ga_pack_item& it = a.it[l];
+    const int r = blockIdx.x - a.row0[l];
+    const int n = it.D1 * it.K;
+    const float* __restrict__ v = it.v + (size_t)r * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s = fmaf(v[i], v[i], s);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float nr = sqrtf(s);
+        it.norm[r] = nr;
+        it.scale[r] = it.g[r] / nr;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackMultiArgs a) {
+    __shared__ float tile[64 * 65];
+    int e = 0;
+    while (e + 1 < 2 * a.n && (int)blockIdx.x >= a.first[e + 1]) ++e;
+    const ga_pack_item& it = a.it[e >> 1];
+    const int lb = blockIdx.x - a.first[e];
+    const float* scale = it.g ? it.scale : nullptr;
+    if (e & 1) pack_one_block<T>(tile, lb, it.v, scale, (T*)it.wp_d, it.mode_d, it.D0, it.D1, it.K, it.S, it.P);
+    else pack_one_block<T>(tile, lb, it.v, scale, (T*)it.wp_f, it.mode_f, it.D0, it.D1, it.K, it.S, it.P);
+}
+
+int ga_pack_multi(const ga_pack_item* items, int n, int dtype, hipStream_t s) {
+    if (!items || n < 1 || n > GA_PACK_MULTI_MAX || (dtype != GA_DTYPE_BF16 && dtype != GA_DTYPE_F32)) return GA_ERR_ARG;
+    PackMultiArgs a;
+    a.n = n;
+    long blocks = 0, rows = 0;
+    for (int l = 0; l < n; ++l) {
+        const ga_pack_item& it = items[l];
+        if (!it.v || !it.wp_f || !it.wp_d || it.D0 <= 0 || it.D1 <= 0 || it.K <= 0) return GA_ERR_ARG;
+        if (it.g && (!it.scale || !it.norm)) return GA_ERR_ARG;
+        for (int which = 0; which < 2; ++which) {
+            const int mode = which ? it.mode_d : it.mode_f;
+            if (mode < 0 || mode > 4) return GA_ERR_ARG;
+            if ((mode == GA_PACK_CONV_DGRAD_STRIDED || mode == GA_PACK_CONVT_FWD) && it.S < 1) return GA_ERR_ARG;
+            if (mode == GA_PACK_CONVT_FWD && it.K != 2 * it.S) return GA_ERR_ARG;
+            a.first[2 * l + which] = (int)blocks;
+            blocks += pack_blocks(mode, it.D0, it.D1, it.K);
+        }
+        a.row0[l] = (int)rows;
+        rows += it.g ? it.D0 : 0;
+        a.it[l] = it;
+        if (blocks > (1L << 30) || rows > (1L << 30)) return GA_ERR_ARG;
+    }
+    a.first[2 * n] = (int)blocks;
+    a.row0[n] = (int)rows;
+    if (rows > 0) {
+        wn_scale_multi_kernel<<<(unsigned)rows, 256, 0, s>>>(a);
+        GA_CHECK_LAUNCH();
+    }
+    if (dtype == GA_DTYPE_BF16) pack_multi_kernel<bf16_t><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else pack_multi_kernel<float><<<(unsigned)blocks, 256, 0, s>>>(a);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
 // weight-norm backward on the effective-weight gradient dw[R][n]:
 //   dg[r] = <dw_r, v_r> / ||v_r||;  dv_r = (g/||v||) * dw_r - (g * <dw_r, v_r> / ||v||^3) * v_r
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,

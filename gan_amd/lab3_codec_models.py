@@ -121,6 +121,9 @@ class CodecLatentTranslator(nn.Module):
         abs_ = torch.baddbmm(b2, hid, w2).unbind(0)                                  # n_f x [B, 2C], contiguous
 
         q = _to_nlc(q_src, dtype)
+        ops.prepack_layers([(self.in_proj.weight, None, self._g_in)]
+                           + [(c.weight, None, g) for blk in self.blocks for c, g in ((blk.conv1, blk.g1), (blk.conv2, blk.g2))]
+                           + [(self.out_proj.weight, None, self._g_out)], dtype)
         h = _conv_train(q, self.in_proj, self._g_in, dtype)
         for i, blk in enumerate(self.blocks):
             r = _conv_train(h, blk.conv1, blk.g1, dtype)
@@ -218,6 +221,7 @@ class MultiScaleWaveDiscriminator(nn.Module):
         if wav.dim() != 3 or wav.shape[1] != 1:
             raise ValueError(f"expected wav [B, 1, S], got {tuple(wav.shape)}")
         outs: List[Tuple[torch.Tensor, List[torch.Tensor]]] = []
+        ops.prepack_layers(self._pack_layers(), dtype)
         x = wav[:, 0, :].to(dtype)  # [B, S]; with C == 1 the NLC and NCL layouts coincide
         for i, d in enumerate(self.discs):
             if i > 0:
@@ -225,6 +229,10 @@ class MultiScaleWaveDiscriminator(nn.Module):
             logits, feats = d.forward_nlc(x.unsqueeze(-1))
             outs.append((logits.permute(0, 2, 1), [f.permute(0, 2, 1) for f in feats]))
         return outs
+
+    def _pack_layers(self):
+        return [(c.weight_v, c.weight_g, g) for d in self.discs
+                for c, g in [(blk.conv, blk.geom) for blk in d.blocks] + [(d.out, d._g_out)]]
 
     def forward_real_fake(self, wav_real: torch.Tensor, wav_fake: torch.Tensor):
         """(D(wav_real) without gradient, D(wav_fake) with gradient to wav_fake only) for FROZEN discriminator weights --
@@ -238,6 +246,7 @@ class MultiScaleWaveDiscriminator(nn.Module):
                 raise ValueError(f"expected wav [B, 1, S], got {tuple(w.shape)}")
         if wav_real.shape[2] != wav_fake.shape[2]:
             raise ValueError("real and fake waveforms differ in length")
+        ops.prepack_layers(self._pack_layers(), dtype)
         xr = wav_real.detach()[:, 0, :].to(dtype)
         xf = wav_fake[:, 0, :].to(dtype)
         real_outs, fake_outs = [], []

@@ -438,6 +438,68 @@ class PackTrainable(torch.autograd.Function):
         return dv, dg, None, None
 
 
+PACK_MULTI = True
+
+
+def prepack_layers(layers, dtype) -> None:
+    """Pack every stale layer of `layers` = [(v, g | None, geom), ...] in two launches (ga_pack_multi) and leave the results
+    in the pack cache, where the per-layer PackTrainable nodes of the forward pass that follows find them.  Layers whose
+    parameters no optimizer has registered (no epoch to stamp a cache entry with) are left to PackTrainable."""
+    if not (PACK_CACHE and PACK_MULTI):
+        return
+    todo = []
+    for v, gparam, geom in layers:
+        if not v.is_contiguous() or v.dtype != torch.float32 or (gparam is not None and not gparam.is_contiguous()):
+            continue
+        holder = _epoch_holder(v.data_ptr())
+        if holder is None:
+            continue
+        key = (v.data_ptr(), geom, dtype)
+        stamp = (holder[0], v._version, None if gparam is None else (gparam.data_ptr(), gparam._version))
+        hit = _PACK_CACHE.get(key)
+        if hit is None or hit[0] != stamp:
+            todo.append((key, stamp, v, gparam, geom))
+    lib = L.lib()
+    for c0 in range(0, len(todo), L.PACK_MULTI_MAX):
+        chunk = todo[c0:c0 + L.PACK_MULTI_MAX]
+        dev = chunk[0][2].device
+        al = 128  # elements: 256-byte (bf16) / 512-byte (fp32) granules
+        sizes_f, sizes_d, rows = [], [], 0
+        for _, _, v, gparam, geom in chunk:
+            d0, d1, k = geom.wdims
+            sizes_f.append((lib.ga_packed_elems(geom.fwd_pack, d0, d1, k, geom.stride) + al - 1) // al * al)
+            sizes_d.append((lib.ga_packed_elems(geom.dgrad_pack, d0, d1, k, geom.stride) + al - 1) // al * al)
+            rows += (d0 + 63) // 64 * 64 if gparam is not None else 0
+        slab_f = torch.empty((sum(sizes_f),), device=dev, dtype=dtype)
+        strided = any(geom.dgrad_pack == L.PACK_CONV_DGRAD_STRIDED for *_, geom in chunk)
+        slab_d = (torch.zeros if strided else torch.empty)((sum(sizes_d),), device=dev, dtype=dtype)
+        sn = torch.empty((2, max(rows, 1)), device=dev, dtype=torch.float32)
+        items = (L.PackItem * len(chunk))()
+        of = od = orow = 0
+        results = []
+        for i, (key, stamp, v, gparam, geom) in enumerate(chunk):
+            d0, d1, k = geom.wdims
+            nf = lib.ga_packed_elems(geom.fwd_pack, d0, d1, k, geom.stride)
+            nd = lib.ga_packed_elems(geom.dgrad_pack, d0, d1, k, geom.stride)
+            wp_f, wp_d = slab_f[of:of + nf], slab_d[od:od + nd]
+            norm = None
+            it = items[i]
+            it.v, it.wp_f, it.wp_d = v.data_ptr(), wp_f.data_ptr(), wp_d.data_ptr()
+            if gparam is not None:
+                scale, norm = sn[0, orow:orow + d0], sn[1, orow:orow + d0]
+                it.g, it.scale, it.norm = gparam.data_ptr(), scale.data_ptr(), norm.data_ptr()
+                orow += (d0 + 63) // 64 * 64
+            it.D0, it.D1, it.K, it.S, it.P = d0, d1, k, geom.stride, geom.padding
+            it.mode_f, it.mode_d = geom.fwd_pack, geom.dgrad_pack
+            of += sizes_f[i]
+            od += sizes_d[i]
+            results.append((key, stamp, wp_f, wp_d, norm))
+        L.check(lib.ga_pack_multi(C.cast(items, C.c_void_p), len(chunk), L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32,
+                                  L.stream()), "ga_pack_multi")
+        for key, stamp, wp_f, wp_d, norm in results:
+            _PACK_CACHE[key] = (stamp, wp_f, wp_d, norm)
+
+
 def pack_frozen(geom: ConvGeom, v: Tensor, gparam: Optional[Tensor], dtype) -> Tuple[Tensor, Tensor]:
     with torch.no_grad():
         scale = None

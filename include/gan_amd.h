@@ -156,6 +156,22 @@ size_t ga_packed_elems(int mode, int D0, int D1, int K, int S);
  * This is where "w = g * v / ||v||" is applied (fused weight-norm), once per step per layer. */
 int ga_pack_weights(const float* src, const float* scale, void* dst, int dtype, int mode, int D0, int D1, int K, int S, int P,
                     ga_stream_t stream);
+/* Both packs (and the weight-norm scale) of up to GA_PACK_MULTI_MAX layers in two launches: what ga_wn_scale +
+ * 2 x ga_pack_weights do per layer, for every conv of a module at once (the per-iteration repack of G's and D's weights,
+ * lab3_codec_models.py:125,143 applied once per optimizer step).  `items` is a HOST array.  Layers with g == NULL are packed
+ * unscaled.  A wp_d written in mode GA_PACK_CONV_DGRAD_STRIDED must be zero-filled by the caller (its padding taps are
+ * not written). */
+#define GA_PACK_MULTI_MAX 24
+typedef struct ga_pack_item {
+    const float* v;  /* [D0][D1][K] fp32 master weights */
+    const float* g;  /* weight-norm gain [D0], or NULL */
+    float* scale;    /* out [D0]: g/||v||   (g != NULL) */
+    float* norm;     /* out [D0]: ||v||     (g != NULL) */
+    void* wp_f;      /* out: pack in mode_f */
+    void* wp_d;      /* out: pack in mode_d */
+    int D0, D1, K, S, P, mode_f, mode_d, reserved;
+} ga_pack_item;
+int ga_pack_multi(const ga_pack_item* items, int n, int dtype, ga_stream_t stream);
 /* dw[s0][s1][k] (+)= packed[pack(s0,s1,k)] : brings a packed-layout gradient back to the parameter layout */
 int ga_unpack_grad(const float* packed, float* dw, int mode, int D0, int D1, int K, int S, int P, int accumulate,
                    ga_stream_t stream);

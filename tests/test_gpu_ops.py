@@ -402,6 +402,40 @@ def test_joined_real_fake_pass_matches_two_passes(precision):
         D.forward_real_fake(xr, xf0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_multi_matches_per_layer_packs(dtype):
+    """ops.prepack_layers (ga_pack_multi: the weight-norm scales and both packs of every layer of a module in two launches)
+    against the per-layer ga_wn_scale + ga_pack_weights calls, bit for bit, on the discriminator's and the generator's
+    layer sets (weight-normed and plain, strided data-gradient packs with zero padding taps, tiny and large weights)."""
+    from gan_amd import lab3_codec_models as M
+    from gan_amd.optim import FusedAdamW
+    torch.manual_seed(12)
+    D = M.MultiScaleWaveDiscriminator(2).to(DEV)
+    G = M.CodecLatentTranslator(hidden_channels=64, n_blocks=13).to(DEV)  # 28 layers: more than one chunk
+    with torch.no_grad():
+        for prm in list(D.parameters()) + list(G.parameters()):
+            prm.mul_(1.0 + 0.1 * torch.rand_like(prm))
+    opts = [FusedAdamW(D.parameters(), lr=1e-4), FusedAdamW(G.parameters(), lr=1e-4)]  # registers the parameter ranges
+    layers = D._pack_layers() + [(G.in_proj.weight, None, G._g_in)] + \
+        [(c.weight, None, g) for blk in G.blocks for c, g in ((blk.conv1, blk.g1), (blk.conv2, blk.g2))] + [(G.out_proj.weight, None, G._g_out)]
+    assert len(layers) == 12 + 28
+    ops._PACK_CACHE.clear()
+    ops.prepack_layers(layers, dtype)
+    for v, gp, geom in layers:
+        hit = ops._PACK_CACHE[(v.data_ptr(), geom, dtype)]
+        scale = None
+        if gp is not None:
+            scale, norm = ops.wn_scale(v, gp)
+            assert torch.equal(hit[3], norm)
+        assert torch.equal(hit[1], ops.pack_weight(geom, v, geom.fwd_pack, dtype, scale)), geom
+        assert torch.equal(hit[2], ops.pack_weight(geom, v, geom.dgrad_pack, dtype, scale)), geom
+    # the forward pass that follows takes the cached packs: no pack kernel is launched again
+    before = dict(ops._PACK_CACHE)
+    ops.prepack_layers(layers, dtype)
+    assert all(ops._PACK_CACHE[k][1] is before[k][1] for k in before)
+    del opts
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
