@@ -46,6 +46,14 @@ class PackItem(C.Structure):
                 ("mode_f", C.c_int), ("mode_d", C.c_int), ("reserved", C.c_int)]
 
 
+class WFinishItem(C.Structure):
+    """ga_wfinish_item (include/gan_amd.h)"""
+    _fields_ = [("gpacked", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("norm", C.c_void_p), ("dv", C.c_void_p),
+                ("dg", C.c_void_p), ("D0", C.c_int), ("D1", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
+
+
+WFINISH_MAX_ROW = 15360
+PACK_CONV_FWD = 0
 PACK_MULTI_MAX = 24
 PACK_CONV_DGRAD_STRIDED = 2
 
@@ -80,6 +88,7 @@ _SIGNATURES = {
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_pack_multi": [_P, _I, _I, _P],
+    "ga_wgrad_finish_multi": [_P, _I, _P],
     "ga_unpack_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_wn_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "ga_gn_stats": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P],

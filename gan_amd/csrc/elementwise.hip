@@ -331,6 +331,73 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
     if (threadIdx.x == 0) dg[r] = accumulate ? dg[r] + s / nr : s / nr;
 }
 
+// ---- weight gradients of a whole module from the packed layout to their final place in one launch ------------------
+// Per layer the backward pass used to run: unpack (packed [D0][K][D1] -> parameter layout), weight-norm backward, and
+// the optimizer's copy of the result into its flat gradient buffer.  One workgroup per weight row does all three: the
+// row's K*D1 packed gradients are contiguous; they are transposed through LDS, dotted with v, and written (scaled and
+// corrected for the weight norm) straight to dv / dg, which the caller points into the flat buffer.
+struct WgFinishArgs {
+    ga_wfinish_item it[GA_PACK_MULTI_MAX];
+    int row0[GA_PACK_MULTI_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_finish_multi_kernel(const WgFinishArgs a) {
+    extern __shared__ float row[];
+    __shared__ float red[16];
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.row0[l + 1]) ++l;
+    const ga_wfinish_item& it = a.it[l];
+    const int r = blockIdx.x - a.row0[l];
+    const int D1 = it.D1, K = it.K, n = D1 * K;
+    const float* __restrict__ gp = it.gpacked + (size_t)r * n;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int k = idx / D1, s1 = idx - k * D1;
+        row[s1 * K + k] = gp[idx];
+    }
+    __syncthreads();
+    float* __restrict__ dv = it.dv + (size_t)r * n;
+    const bool acc_v = it.accumulate & 1;
+    if (!it.g) {
+        for (int i = threadIdx.x; i < n; i += 256) dv[i] = acc_v ? dv[i] + row[i] : row[i];
+        return;
+    }
+    const float* __restrict__ v = it.v + (size_t)r * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s = fmaf(row[i], v[i], s);
+    s = block_sum(s, red);
+    const float nr = it.norm[r], gr = it.g[r];
+    const float ca = gr / nr, cb = gr * s / (nr * nr * nr);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float val = ca * row[i] - cb * v[i];
+        dv[i] = acc_v ? dv[i] + val : val;
+    }
+    if (threadIdx.x == 0) it.dg[r] = (it.accumulate & 2) ? it.dg[r] + s / nr : s / nr;
+}
+
+int ga_wgrad_finish_multi(const ga_wfinish_item* items, int n, hipStream_t s) {
+    if (!items || n < 1 || n > GA_PACK_MULTI_MAX) return GA_ERR_ARG;
+    WgFinishArgs a;
+    a.n = n;
+    long rows = 0;
+    int nmax = 0;
+    for (int l = 0; l < n; ++l) {
+        const ga_wfinish_item& it = items[l];
+        if (!it.gpacked || !it.dv || it.D0 <= 0 || it.D1 <= 0 || it.K <= 0) return GA_ERR_ARG;
+        if ((long)it.D1 * it.K > GA_WFINISH_MAX_ROW) return GA_ERR_ARG;
+        if (it.g && (!it.v || !it.norm || !it.dg)) return GA_ERR_ARG;
+        a.it[l] = it;
+        a.row0[l] = (int)rows;
+        rows += it.D0;
+        if (it.D1 * it.K > nmax) nmax = it.D1 * it.K;
+        if (rows > (1L << 30)) return GA_ERR_ARG;
+    }
+    a.row0[n] = (int)rows;
+    wgrad_finish_multi_kernel<<<(unsigned)rows, 256, (size_t)nmax * sizeof(float), s>>>(a);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
 // 16 bytes of T (4 floats / 8 bf16)
 template <typename T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
 

@@ -214,8 +214,15 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
         loss.backward()
         dp.finish_backward(opt)
         return
-    loss.backward()
+    sink = ops.WeightGradSink(opt) if (ops.WGRAD_SINK and loss.is_cuda) else None
+    ops._SINK = sink
+    try:
+        loss.backward()
+    finally:
+        ops._SINK = None
     opt.gather_grads()
+    if sink is not None:
+        sink.flush()  # the conv weights' gradients go from the packed layout straight into opt.flat_g
     if dp is not None:
         dp.allreduce_flat(opt)
 

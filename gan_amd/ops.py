@@ -381,6 +381,54 @@ def zeros_f32(n: int, device) -> Tensor:
     return out
 
 
+# ---- deferred weight gradients ---------------------------------------------------------------------
+# While a WeightGradSink is active (lab3_codec_train._backward_and_reduce installs one around loss.backward()), the
+# PackTrainable nodes of layers whose parameters belong to the sink's optimizer do not unpack / weight-norm-backward /
+# return their gradient one layer at a time: they hand the packed gradient to the sink, and flush() takes all of them to
+# their final place in the optimizer's flat gradient buffer in one launch (ga_wgrad_finish_multi).  p.grad of those
+# parameters stays as it was (None after zero_grad): the flat buffer is what the optimizer and the all-reduce read.
+WGRAD_SINK = True
+_SINK = None
+
+
+class WeightGradSink:
+    def __init__(self, opt):
+        self.opt = opt
+        m = getattr(opt, "_sink_map", None)
+        if m is None:
+            m = opt._sink_map = {p.data_ptr(): i for i, p in enumerate(opt.params)}
+        self.index = m
+        self.pending = {}
+
+    def offer(self, v, gparam, norm, geom, gpacked) -> bool:
+        d0, d1, k = geom.wdims
+        if geom.fwd_pack != L.PACK_CONV_FWD or d1 * k > L.WFINISH_MAX_ROW or gpacked.dtype != torch.float32:
+            return False
+        iv = self.index.get(v.data_ptr())
+        ig = None if gparam is None else self.index.get(gparam.data_ptr())
+        if iv is None or (gparam is not None and ig is None) or iv in self.pending:
+            return False
+        self.pending[iv] = (ig, v, gparam, norm, (d0, d1, k), gpacked.contiguous())
+        return True
+
+    def flush(self) -> None:
+        """after opt.gather_grads(): add (p.grad present: it has been copied in) or write (absent) the deferred gradients"""
+        todo = list(self.pending.items())
+        self.pending = {}
+        opt, lib = self.opt, L.lib()
+        for c0 in range(0, len(todo), L.PACK_MULTI_MAX):
+            chunk = todo[c0:c0 + L.PACK_MULTI_MAX]
+            items = (L.WFinishItem * len(chunk))()
+            for it, (iv, (ig, v, gparam, norm, (d0, d1, k), gpacked)) in zip(items, chunk):
+                it.gpacked, it.dv = gpacked.data_ptr(), opt.grad_views[iv].data_ptr()
+                it.D0, it.D1, it.K = d0, d1, k
+                it.accumulate = 1 if opt.params[iv].grad is not None else 0
+                if gparam is not None:
+                    it.v, it.g, it.norm, it.dg = v.data_ptr(), gparam.data_ptr(), norm.data_ptr(), opt.grad_views[ig].data_ptr()
+                    it.accumulate |= 2 if opt.params[ig].grad is not None else 0
+            L.check(lib.ga_wgrad_finish_multi(C.cast(items, C.c_void_p), len(chunk), L.stream()), "ga_wgrad_finish_multi")
+
+
 class PackTrainable(torch.autograd.Function):
     """(v, g | None) -> (forward pack, data-gradient pack) in the activation dtype.  Backward takes the
     packed-forward-layout gradient from the weight-gradient kernel back to the parameter layout and through
@@ -425,6 +473,8 @@ class PackTrainable(torch.autograd.Function):
         geom = ctx.geom
         d0, d1, k = geom.wdims
         if gwp_f is None:
+            return None, None, None, None
+        if _SINK is not None and _SINK.offer(v, gparam if ctx.has_g else None, norm, geom, gwp_f):
             return None, None, None, None
         dw = torch.empty_like(v)
         L.check(L.lib().ga_unpack_grad(gwp_f.contiguous().data_ptr(), dw.data_ptr(), geom.fwd_pack, d0, d1, k, geom.stride,

@@ -172,6 +172,22 @@ typedef struct ga_pack_item {
     int D0, D1, K, S, P, mode_f, mode_d, reserved;
 } ga_pack_item;
 int ga_pack_multi(const ga_pack_item* items, int n, int dtype, ga_stream_t stream);
+/* The weight gradients of up to GA_PACK_MULTI_MAX Conv1d layers, from the packed GA_PACK_CONV_FWD layout [D0][K][D1]
+ * (what ga_wgrad writes) to their final place, in one launch: ga_unpack_grad + ga_wn_bwd per layer, and the copy into the
+ * optimizer's gradient buffer, fused (torch weight_norm backward, lab3_codec_models.py:125,143; opt step,
+ * lab3_codec_train.py:444-452,585-590).  g == NULL: plain layer, dv = unpacked gradient.  accumulate bit 0: add to dv,
+ * bit 1: add to dg.  D1*K <= GA_WFINISH_MAX_ROW (one weight row is staged in LDS).  `items` is a HOST array. */
+#define GA_WFINISH_MAX_ROW 15360
+typedef struct ga_wfinish_item {
+    const float* gpacked; /* [D0][K][D1] fp32 */
+    const float* v;       /* [D0][D1][K]   (g != NULL) */
+    const float* g;       /* [D0] or NULL */
+    const float* norm;    /* [D0] ||v||    (g != NULL) */
+    float* dv;            /* out [D0][D1][K] */
+    float* dg;            /* out [D0]      (g != NULL) */
+    int D0, D1, K, accumulate;
+} ga_wfinish_item;
+int ga_wgrad_finish_multi(const ga_wfinish_item* items, int n, ga_stream_t stream);
 /* dw[s0][s1][k] (+)= packed[pack(s0,s1,k)] : brings a packed-layout gradient back to the parameter layout */
 int ga_unpack_grad(const float* packed, float* dw, int mode, int D0, int D1, int K, int S, int P, int accumulate,
                    ga_stream_t stream);

@@ -436,6 +436,48 @@ def test_pack_multi_matches_per_layer_packs(dtype):
     del opts
 
 
+@pytest.mark.parametrize("preset_grad", [False, True])
+def test_deferred_weight_gradients_match_per_layer_path(preset_grad):
+    """ops.WeightGradSink + ga_wgrad_finish_multi (unpack + weight-norm backward + copy into the optimizer's flat gradient
+    buffer, all conv layers of a module in one launch) against the per-layer autograd path: the flat gradient buffer after
+    _backward_and_reduce, for the weight-normed discriminator and the plain-conv generator; with gradients already present
+    in p.grad (the R1 term puts them there before the hinge backward) the deferred ones must add to them."""
+    from gan_amd import lab3_codec_models as M
+    from gan_amd.lab3_codec_train import _backward_and_reduce
+    from gan_amd.optim import FusedAdamW
+    torch.manual_seed(21)
+    D = M.MultiScaleWaveDiscriminator(2, precision="bf16").to(DEV)
+    G = M.CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(DEV)
+    opt_d, opt_g = FusedAdamW(D.parameters(), lr=1e-4), FusedAdamW(G.parameters(), lr=1e-4)
+    wav = torch.randn(3, 1, 5003, device=DEV)
+    q, zc, zs, nz = torch.randn(2, 128, 29, device=DEV), torch.randn(2, 128, device=DEV), torch.randn(2, 128, device=DEV), torch.randn(2, 32, device=DEV)
+
+    def flat(sink_on, which):
+        ops.WGRAD_SINK = sink_on
+        opt = opt_d if which == "d" else opt_g
+        opt.zero_grad(set_to_none=True)
+        if preset_grad:
+            for i, prm in enumerate(opt.params):
+                prm.grad = torch.full_like(prm, 0.01 * (i + 1))
+        torch.manual_seed(3)
+        if which == "d":
+            loss = sum((lg.float() * torch.randn_like(lg.float())).sum() + sum((f.float() * torch.randn_like(f.float())).mean() for f in fs)
+                       for lg, fs in D(wav))
+        else:
+            out = G(q_src=q, z_content=zc, z_style_tgt=zs, noise=nz)
+            loss = (out.float() * torch.randn_like(out.float())).sum()
+        _backward_and_reduce(loss, opt, None)
+        return opt.flat_g.clone()
+
+    try:
+        for which in ("d", "g"):
+            a, b = flat(True, which), flat(False, which)
+            assert float(b.abs().max()) > 0
+            close(a.cpu(), b.cpu(), 2e-5, f"flat gradient buffer ({which})")
+    finally:
+        ops.WGRAD_SINK = True
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
