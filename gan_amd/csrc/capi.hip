@@ -35,6 +35,10 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     // thin bf16 layers (M <= 64, K <= 192): the register-streaming MFMA kernel, which is also the one that fuses ELU(x)
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_stream_impl(p, s);
+    if (p.res_mode != GA_RES_ADD) {  // only the gathered-GEMM kernel's epilogue forms the feature-matching term
+        if (p.res_mode != GA_RES_FM_SIGN || !p.res || !p.dact_src || !p.dact_mode || !p.res_coef_dev) return GA_ERR_ARG;
+        return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
+    }
     if (p.y_batch_elems != 0 && !(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return GA_ERR_ARG;
     if (p.y_batch_elems != 0) return ga_conv_gemm_impl(p, s);
     if (p.ksplit > 1) return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
@@ -70,6 +74,10 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
     const bool big = (long)p.Lout * p.B >= 64 || p.out_f32;
+    if (p.res_mode != GA_RES_ADD) {  // ga_conv: gathered-GEMM kernel or nothing
+        if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
+        return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
+    }
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return GA_KERNEL_STREAM;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
     const bool simple_act = p.post_act == GA_ACT_NONE || p.post_act == GA_ACT_LRELU;
     const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
+    const float fm_c = (p.res_mode == GA_RES_FM_SIGN && ksplit == 1) ? p.res_coef * p.res_coef_dev[0] : 0.f;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -331,15 +332,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i] + bv[i]);
             }
-            if (p.dact_mode) {
+            if (p.res_mode == GA_RES_FM_SIGN) {  // (v + c * sign(fake - real)) * dact(fake)
                 const bf16x8 d = *(const bf16x8*)(ds + o);
+                const bf16x8 rr = *(const bf16x8*)(res + o);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
-            }
-            if (res) {
-                const bf16x8 d = *(const bf16x8*)(res + o);
+                for (int i = 0; i < 8; ++i) {
+                    const float f = (float)d[i], q = (float)rr[i];
+                    v[i] = (v[i] + (f > q ? fm_c : f < q ? -fm_c : 0.f)) * dact_apply(p.dact_mode, f);
+                }
+            } else {
+                if (p.dact_mode) {
+                    const bf16x8 d = *(const bf16x8*)(ds + o);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+                    for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
+                }
+                if (res) {
+                    const bf16x8 d = *(const bf16x8*)(res + o);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+                }
             }
             if (p.accumulate) {
                 const bf16x8 d = *(const bf16x8*)(y + o);
@@ -390,15 +401,26 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, long tot
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i]);
-        if (p.dact_mode) {
+        if (p.res_mode == GA_RES_FM_SIGN) {
+            const float fm_c = p.res_coef * p.res_coef_dev[0];
             const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.dact_src + o);
+            const bf16x8 rr = *(const bf16x8*)((const bf16_t*)p.res + o);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
-        }
-        if (p.res) {
-            const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.res + o);
+            for (int i = 0; i < 8; ++i) {
+                const float f = (float)d[i], q = (float)rr[i];
+                v[i] = (v[i] + (f > q ? fm_c : f < q ? -fm_c : 0.f)) * dact_apply(p.dact_mode, f);
+            }
+        } else {
+            if (p.dact_mode) {
+                const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.dact_src + o);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+                for (int i = 0; i < 8; ++i) v[i] *= dact_apply(p.dact_mode, (float)d[i]);
+            }
+            if (p.res) {
+                const bf16x8 d = *(const bf16x8*)((const bf16_t*)p.res + o);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+            }
         }
         if (p.out_f32) {
             float* yo = (float*)p.y + o;

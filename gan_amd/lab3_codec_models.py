@@ -189,17 +189,19 @@ class SingleScaleWaveDiscriminator(nn.Module):
         outs = ops.DiscChain.apply(x, tuple(g for _, g in convs), *flat)
         return outs[-1], list(outs[:-1])
 
-    def forward_real_fake_nlc(self, x_real: torch.Tensor, x_fake: torch.Tensor):
-        """G-step pair of passes as one (ops.DiscChainSplit): ((logits, feats) of x_real without gradient, the same of x_fake)."""
+    def forward_real_fake_nlc(self, x_real: torch.Tensor, x_fake: torch.Tensor, want_fm: bool = False):
+        """G-step pair of passes as one (ops.DiscChainSplit): ((logits, feats) of x_real without gradient, the same of x_fake
+        [, this scale's feature-matching term when want_fm])."""
         convs = [(blk.conv, blk.geom) for blk in self.blocks] + [(self.out, self._g_out)]
         flat = []
         with torch.no_grad():
             for conv, geom in convs:
                 wp_f, wp_d, _ = ops.PackTrainable.apply(conv.weight_v, conv.weight_g, geom, x_fake.dtype)
                 flat += [wp_f, wp_d, conv.bias]
-        outs = ops.DiscChainSplit.apply(x_real, x_fake, tuple(g for _, g in convs), *flat)
+        outs = ops.DiscChainSplit.apply(x_real, x_fake, tuple(g for _, g in convs), bool(want_fm), *flat)
         n = len(convs)
-        return (outs[n - 1], list(outs[:n - 1])), (outs[2 * n - 1], list(outs[n:2 * n - 1]))
+        pair = (outs[n - 1], list(outs[:n - 1])), (outs[2 * n - 1], list(outs[n:2 * n - 1]))
+        return pair + (outs[2 * n],) if want_fm else pair
 
     def forward(self, wav: torch.Tensor) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         logits, feats = self.forward_nlc(wav.permute(0, 2, 1).contiguous())
@@ -234,9 +236,12 @@ class MultiScaleWaveDiscriminator(nn.Module):
         return [(c.weight_v, c.weight_g, g) for d in self.discs
                 for c, g in [(blk.conv, blk.geom) for blk in d.blocks] + [(d.out, d._g_out)]]
 
-    def forward_real_fake(self, wav_real: torch.Tensor, wav_fake: torch.Tensor):
+    def forward_real_fake(self, wav_real: torch.Tensor, wav_fake: torch.Tensor, want_fm: bool = False):
         """(D(wav_real) without gradient, D(wav_fake) with gradient to wav_fake only) for FROZEN discriminator weights --
-        the generator step's two passes (reference lab3_codec_train.py:455-462) run as one pass over the joined batch."""
+        the generator step's two passes (reference lab3_codec_train.py:455-462) run as one pass over the joined batch.
+        want_fm: a third result, multiscale_feature_matching_loss(real_outs, fake_outs), whose reductions run inside the
+        same autograd nodes and whose gradient is formed in the data-gradient epilogues (the features returned for the
+        fake half still carry gradient for any other use)."""
         L.require_cuda(wav_real, wav_fake)
         if any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("forward_real_fake needs the discriminator's parameters frozen (requires_grad False)")
@@ -249,15 +254,20 @@ class MultiScaleWaveDiscriminator(nn.Module):
         ops.prepack_layers(self._pack_layers(), dtype)
         xr = wav_real.detach()[:, 0, :].to(dtype)
         xf = wav_fake[:, 0, :].to(dtype)
-        real_outs, fake_outs = [], []
+        real_outs, fake_outs, fm_terms = [], [], []
         for i, d in enumerate(self.discs):
             if i > 0:
                 with torch.no_grad():
                     xr = ops.AvgPool4s2.apply(xr)
                 xf = ops.AvgPool4s2.apply(xf)
-            (lr, fr), (lf, ff) = d.forward_real_fake_nlc(xr.unsqueeze(-1), xf.unsqueeze(-1))
+            res = d.forward_real_fake_nlc(xr.unsqueeze(-1), xf.unsqueeze(-1), want_fm)
+            (lr, fr), (lf, ff) = res[0], res[1]
+            if want_fm:
+                fm_terms.append(res[2])
             real_outs.append((lr.permute(0, 2, 1), [f.permute(0, 2, 1) for f in fr]))
             fake_outs.append((lf.permute(0, 2, 1), [f.permute(0, 2, 1) for f in ff]))
+        if want_fm:
+            return real_outs, fake_outs, torch.stack(fm_terms).sum() / max(1, len(fm_terms))
         return real_outs, fake_outs
 
 

@@ -304,8 +304,9 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     try:
         if hasattr(discriminator, "forward_real_fake"):
             # D(real) under no_grad and D(fake) (:455-462) as one pass over the joined batch
-            real_outs_g, fake_outs = discriminator.forward_real_fake(x_real_g, x_hat)
+            real_outs_g, fake_outs, loss_fm = discriminator.forward_real_fake(x_real_g, x_hat, want_fm=True)
         else:
+            loss_fm = None
             with torch.no_grad():
                 real_outs_g = discriminator(x_real_g)
             fake_outs = discriminator(x_hat)
@@ -314,7 +315,8 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
             p.requires_grad_(r)
 
     loss_adv = multiscale_hinge_g_loss(fake_outs=fake_outs)
-    loss_fm = multiscale_feature_matching_loss(real_outs=real_outs_g, fake_outs=fake_outs)
+    if loss_fm is None:
+        loss_fm = multiscale_feature_matching_loss(real_outs=real_outs_g, fake_outs=fake_outs)
     loss_lat_l1, loss_lat_cont, loss_delta_budget = latent_losses(q_hat, q_src, float(stage_cfg.delta_budget))
     loss_mrstft = _waveform_mrstft_loss(wav_pred=x_hat, wav_true=x_src, resolutions=stage_cfg.wave_mrstft_resolutions,
                                         sum_hook=None if dp is None else dp.stft_sum_hook,

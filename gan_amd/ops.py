@@ -250,10 +250,15 @@ def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre
     return y
 
 
-def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dact_src=None, res=None) -> Tensor:
+def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dact_src=None, res=None, fm_coef=None) -> Tensor:
+    """fm_coef = (scale, device scalar): `res` is the real feature map paired with the fake one in dact_src and the
+    epilogue adds scale * scalar * sign(dact_src - res) before the mask (GA_RES_FM_SIGN; check fm_sign_fusable first)."""
     B = gy.shape[0]
     p = dgrad_params(g, B, lin)
     p.dact_mode = dact_mode
+    if fm_coef is not None:
+        assert g.kind == "conv" and res is not None and dact_src is not None and dact_mode
+        p.res_mode, p.res_coef, p.res_coef_dev = L.RES_FM_SIGN, float(fm_coef[0]), fm_coef[1].data_ptr()
     dx = torch.empty((B, lin, g.cin), device=gy.device, dtype=gy.dtype)
     _launch_conv(p, gy, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL)
     if g.kind == "cconv" and g.k > 1:
@@ -268,6 +273,19 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
             fix_impl = L.IMPL_MFMA if kid in L.GEMM_KERNELS else L.IMPL_DIRECT
             _launch_conv(q, gy, wp_d, dx, dact_src=dact_src, impl=fix_impl)
     return dx
+
+
+def fm_sign_fusable(g: ConvGeom, gy: Tensor, lin: int) -> bool:
+    """True when ga_conv runs this layer's data gradient on the gathered-GEMM kernel, whose epilogue can form the
+    feature-matching gradient (GA_RES_FM_SIGN)."""
+    if gy.dtype != torch.bfloat16 or _IMPL not in (L.IMPL_AUTO, L.IMPL_MFMA) or g.kind != "conv":
+        return False
+    p = dgrad_params(g, gy.shape[0], lin)
+    p.dact_mode, p.res_mode = L.DACT_LRELU_FROM_OUT, L.RES_FM_SIGN
+    p.x = p.w = p.y = p.res = p.dact_src = p.res_coef_dev = 256  # alignment checks only: nothing is dereferenced
+    if MERGE_PHASES:
+        p, _ = _fold_phases(p, gy, None)
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(gy), _IMPL) in (7, 8, 9)
 
 
 def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):
@@ -696,7 +714,7 @@ class DiscChainSplit(torch.autograd.Function):
     outputs: n real-half tensors (features then logits; non-differentiable), then the n fake-half tensors."""
 
     @staticmethod
-    def forward(ctx, x_real, x_fake, geoms, *flat):
+    def forward(ctx, x_real, x_fake, geoms, want_fm, *flat):
         n = len(geoms)
         assert len(flat) == 3 * n
         b0 = int(x_real.shape[0])
@@ -710,7 +728,22 @@ class DiscChainSplit(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         real = tuple(o[:b0] for o in outs)
         ctx.mark_non_differentiable(*real)
-        return real + tuple(o[b0:] for o in outs)
+        ctx.want_fm = bool(want_fm)
+        if not want_fm:
+            return real + tuple(o[b0:] for o in outs)
+        # feature matching of this scale, (1/n_feats) * sum_l mean|fake_l - real_l| (lab3_codec_models.py:191-199), summed
+        # into one scalar here; its gradient is formed inside the data-gradient epilogues of backward()
+        if x_fake.shape[0] != b0:
+            raise ValueError("feature matching needs as many real as fake items")
+        fm = zeros_f32(1, h.device)
+        ctx.fm_scales = []
+        for o in outs[:-1]:
+            half = o[b0:]
+            sc = 1.0 / (half.numel() * max(1, n - 1))
+            ctx.fm_scales.append(sc)
+            L.check(L.lib().ga_reduce(half.data_ptr(), o.data_ptr(), L.dt(o), half.numel(), L.RED_ABSDIFF, sc, fm.data_ptr(),
+                                      L.stream()), "ga_reduce")
+        return real + tuple(o[b0:] for o in outs) + (fm.view(()),)
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -719,24 +752,38 @@ class DiscChainSplit(torch.autograd.Function):
         saved = ctx.saved_tensors
         feats = saved[:n - 1]
         wp_d = saved[n - 1:]
-        gouts = gouts[n:]
-        grads = [None] * (3 + 3 * n)
-        if any(ctx.needs_input_grad[3:]):
+        g_fm = gouts[2 * n] if ctx.want_fm else None
+        gouts = gouts[n:2 * n]
+        grads = [None] * (4 + 3 * n)
+        if any(ctx.needs_input_grad[4:]):
             raise RuntimeError("DiscChainSplit is for frozen discriminator weights")
         dtype = wp_d[0].dtype
+        if g_fm is not None:
+            g_fm = g_fm.reshape(1).float().contiguous()
         ga = gouts[n - 1]
         if ga is not None:
             ga = ga.contiguous().to(dtype)
         for l in range(n - 1, -1, -1):
             g_feat = gouts[l - 1] if l > 0 else None
-            if ga is None and g_feat is None:
+            if ga is None and g_feat is None and (g_fm is None or l == 0):
                 continue
             if l == 0:
                 if ga is not None and ctx.needs_input_grad[1]:
                     grads[1] = conv_dgrad(geoms[0], ga, wp_d[0], ctx.len0)
                 break
-            y_prev = feats[l - 1][b0:]
+            y_prev, r_prev = feats[l - 1][b0:], feats[l - 1][:b0]
             extra = act_bwd(g_feat.contiguous().to(dtype), y_prev, L.DACT_LRELU_FROM_OUT) if g_feat is not None else None
+            if g_fm is not None:
+                if ga is not None and extra is None and fm_sign_fusable(geoms[l], ga, y_prev.shape[1]):
+                    # (dgrad + c * sign(fake - real)) * lrelu'(fake), all in the data-gradient epilogue
+                    ga = conv_dgrad(geoms[l], ga, wp_d[l], y_prev.shape[1], dact_mode=L.DACT_LRELU_FROM_OUT, dact_src=y_prev,
+                                    res=r_prev, fm_coef=(ctx.fm_scales[l - 1], g_fm))
+                    continue
+                gf = torch.empty_like(y_prev)
+                L.check(L.lib().ga_reduce_grad(y_prev.data_ptr(), r_prev.data_ptr(), L.dt(y_prev), y_prev.numel(), L.RED_ABSDIFF,
+                                               g_fm.data_ptr(), ctx.fm_scales[l - 1], gf.data_ptr(), 0, L.stream()), "ga_reduce_grad")
+                gf = act_bwd(gf, y_prev, L.DACT_LRELU_FROM_OUT)
+                extra = gf if extra is None else extra + gf
             if ga is not None:
                 ga = conv_dgrad(geoms[l], ga, wp_d[l], y_prev.shape[1], dact_mode=L.DACT_LRELU_FROM_OUT, dact_src=y_prev, res=extra)
             else:

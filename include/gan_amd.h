@@ -84,7 +84,15 @@ typedef struct ga_conv_params {
                     only) that distance AND the number of valid elements per item: lets the output phases of a strided
                     data gradient / transposed conv be folded into M (rows of nphase*M channels, which is the same
                     memory as nphase rows of M) when the item length is not a multiple of nphase */
+    int res_mode;   /* GA_RES_ADD (0): epi adds res.  GA_RES_FM_SIGN (MFMA GEMM kernel only; needs dact_mode, dact_src, res
+                    and res_coef_dev): res holds the REAL feature map that pairs with the fake one in dact_src, and epi adds
+                    res_coef * res_coef_dev[0] * sign(dact_src - res) * dact(dact_src) -- the feature-matching L1 gradient
+                    (lab3_codec_models.py:191-199) formed in the data-gradient epilogue instead of in two passes of its own */
+    float res_coef;
+    const float* res_coef_dev; /* device scalar (the loss term's upstream gradient) */
 } ga_conv_params;
+#define GA_RES_ADD 0
+#define GA_RES_FM_SIGN 1
 
 /* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients
  *   G   lab3_codec_models.py:31-32,75,86 (k3, dilation 1/2/4/8)

@@ -396,6 +396,21 @@ def test_joined_real_fake_pass_matches_two_passes(precision):
             close(b.float().cpu(), a.float().cpu(), tol, "feature")
     assert all(not t.requires_grad for lg, fs in r_new for t in [lg] + fs)
     close(xf2.grad.cpu(), g_ref.cpu(), tol, "fake waveform gradient")
+    # feature matching inside the node (reductions in forward, gradient in the data-gradient epilogues) against
+    # multiscale_feature_matching_loss on the two-pass outputs; equal halves, with and without a logits term
+    xr3 = torch.randn(3, 1, 6007, device=DEV)
+    for w_adv in (0.5, 0.0):
+        xa = xf0.clone().requires_grad_(True)
+        with torch.no_grad():
+            r_ref = D(xr3)
+        f_ref = D(xa)
+        fm_ref = M.multiscale_feature_matching_loss(r_ref, f_ref)
+        (1.7 * fm_ref + w_adv * M.multiscale_hinge_g_loss(f_ref)).backward()
+        xb = xf0.clone().requires_grad_(True)
+        r_new, f_new, fm_new = D.forward_real_fake(xr3, xb, want_fm=True)
+        (1.7 * fm_new + w_adv * M.multiscale_hinge_g_loss(f_new)).backward()
+        assert float(fm_new) == pytest.approx(float(fm_ref), rel=1e-5 if precision == "fp32" else 1e-3)
+        close(xb.grad.cpu(), xa.grad.cpu(), tol, f"fake waveform gradient with feature matching (adv weight {w_adv})")
     for prm in D.parameters():
         prm.requires_grad_(True)
     with pytest.raises(RuntimeError):
