@@ -44,6 +44,11 @@ __device__ __forceinline__ void divmod_small(int n, int d, float rcp, int& q, in
 }
 
 // MI: 32-row MFMA tiles per wave along m (2: wave tile 64 x 64, 1: wave tile 32 x 64 for layers with <= 32 output channels)
+#ifndef GA_GEMM_SETPRIO
+#define GA_GEMM_SETPRIO 0  // measured: no change in kernel time at 1-3 workgroups per CU
+#endif
+static constexpr bool SETPRIO = GA_GEMM_SETPRIO;
+
 template <int MI, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
     constexpr int WMR = MI * 32;               // rows (m) per wave
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
         }
         const char* Ab = Al + buf * (BM * 128) + aoff;
         const char* Bb = Bl + buf * (BN * 128) + boff;
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int po = ((kk * 2 + h) ^ swz) << 4;
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (NBUF >= 2 && ++buf == NBUF) buf = 0;
     }
 

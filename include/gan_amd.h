@@ -123,7 +123,7 @@ int ga_conv_finish(const ga_conv_params* h_params, int dtype, ga_stream_t stream
 #define GA_KERNEL_THIN_FEWOUT_ROWS 5
 #define GA_KERNEL_THIN_CIN1_VEC 6
 #define GA_KERNEL_GEMM_64x256 7  /* conv_gemm_kernel<2,1,4> */
-#define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2,2> */
+#define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2,2>; <1,2,2> (64x128 tiles) for grids of few workgroups */
 #define GA_KERNEL_GEMM_32x256 9  /* conv_gemm_kernel<1,1,4> */
 #define GA_KERNEL_STREAM 10      /* conv_stream_kernel: M <= 64, K <= 192, operands straight from global memory */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
