@@ -44,17 +44,24 @@ __device__ __forceinline__ void divmod_small(int n, int d, float rcp, int& q, in
 }
 
 // MI: 32-row MFMA tiles per wave along m (2: wave tile 64 x 64, 1: wave tile 32 x 64 for layers with <= 32 output channels)
+// waves per SIMD the single-buffer 128x128 instantiation is compiled for (4: 128 registers, four workgroups per CU hide
+// each other's load round trips; 3: 144 registers, no spills)
+#ifndef GA_GEMM_NBUF1_WAVES
+#define GA_GEMM_NBUF1_WAVES 4
+#endif
 #ifndef GA_GEMM_SETPRIO
 #define GA_GEMM_SETPRIO 0  // measured: no change in kernel time at 1-3 workgroups per CU
 #endif
 static constexpr bool SETPRIO = GA_GEMM_SETPRIO;
 
 template <int MI, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
+__global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && MI == 2) ? GA_GEMM_NBUF1_WAVES : 1)) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
     constexpr int WMR = MI * 32;               // rows (m) per wave
     constexpr int BM = WM * WMR, BN = WN * 64;
-    constexpr int NA = (BM * 8 + 255) / 256;   // 16-byte pieces per thread per K-step, A (weights)
-    constexpr int NB = BN * 8 / 256;           // same, B (gathered activations)
+    constexpr int NT = WM * WN * 64;           // threads: WM x WN waves (4, or 8 for the 256x128 tile)
+    constexpr int RPI = NT / 8;                // tile rows one load instruction of the workgroup covers
+    constexpr int NA = (BM * 8 + NT - 1) / NT; // 16-byte pieces per thread per K-step, A (weights)
+    constexpr int NB = BN * 8 / NT;            // same, B (gathered activations)
     constexpr int EPF = WMR + 4;               // floats per staged epilogue row (odd number of 16-byte slots)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     // [NBUF][BM*128] A, then [NBUF][BN*128] B; reused by the epilogue as 4 x [32][EPF] floats
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     const bf16_t* __restrict__ w = (const bf16_t*)p.w + (size_t)phase * p.M * Ktot;
     const uintptr_t zero = (uintptr_t)ga_zero_page;
 
-    // staging geometry: piece q = i*256 + tid -> row q>>3 = i*32 + (tid>>3), slot tid&7, logical piece below
+    // staging geometry: piece q = i*NT + tid -> row q>>3 = i*RPI + (tid>>3), slot tid&7, logical piece below
     const int srow = tid >> 3;
     const int piece = (tid & 7) ^ ((tid >> 4) & 7);
     // per-thread gather state.  The K position advances by 64 per stage, so tap j, channel c and the byte offset of
@@ -114,15 +121,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
     uintptr_t abase[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = mbase + i * 32 + srow;
-        abase[i] = (m < p.M && i * 32 + srow < BM) ? (uintptr_t)(w + (size_t)m * Ktot) : 0;
+        const int m = mbase + i * RPI + srow;
+        abase[i] = (m < p.M && i * RPI + srow < BM) ? (uintptr_t)(w + (size_t)m * Ktot) : 0;
     }
     uintptr_t xitem[NB];  // start of the row's batch item (0: row past the end)
     uintptr_t rb[NB];     // xitem + bR*Cin elements: address of (tap 0, channel 0) of the row's window, possibly out of range
     int bR[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = nbase + i * 32 + srow;
+        const int n = nbase + i * RPI + srow;
         int b, tl;
         divmod_small(n < Ntot ? n : 0, p.Lout, rcpL, b, tl);
         xitem[i] = n < Ntot ? (uintptr_t)((const bf16_t*)p.x + (size_t)b * p.Lin * Cin) : 0;
@@ -162,14 +169,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
         char* const bb = Bl + buf * (BN * 128) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            glds16(sel_addr(kin && abase[i], abase[i] + (uintptr_t)(st_k * 2), zero), ab + i * 4096);
+            glds16(sel_addr(kin && abase[i], abase[i] + (uintptr_t)(st_k * 2), zero), ab + i * (NT * 16));
         }
         if (!reflect) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int R = bR[i] + st_dR;
                 const bool ok = kin && xitem[i] && R >= 0 && R < p.Lin;
-                glds16(sel_addr(ok, rb[i] + (uintptr_t)(long)st_kk, zero), bb + i * 4096);
+                glds16(sel_addr(ok, rb[i] + (uintptr_t)(long)st_kk, zero), bb + i * (NT * 16));
             }
         } else {
 #pragma unroll
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
                 int R = bR[i] + st_dR;
                 if (R < 0) R = -R;
                 const bool ok = kin && xitem[i] && R < p.Lin;
-                glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * 4096);
+                glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * (NT * 16));
             }
         }
         if (tapfast) {
@@ -245,9 +252,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p, int nN, in
         } else if (NBUF == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            const int ahead = ks_end - 1 - ks;  // stages issued after stage ks
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            const int ahead = ks_end - 1 - ks;  // stages issued after stage ks (at most DEPTH - 1 of them are in flight here)
+            if (DEPTH >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (NBUF > 2) {
@@ -516,6 +523,25 @@ static int gemm_half_max_blocks() {
     return v;
 }
 
+// GA_GEMM_WIDE: 0 = never use the 256x128 eight-wave tile, 2 / 3 = use it with that many LDS buffers (tuning aid)
+static int gemm_wide_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_WIDE");
+        v = e ? atoi(e) : 0;
+        if (v != 2 && v != 3) v = 0;
+    }
+    return v;
+}
+static int gemm_wide_min_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_WIDE_MIN");
+        v = e ? atoi(e) : 600;
+    }
+    return v;
+}
+
 // m-tiles per group in the tile order (see the kernel); GA_GEMM_MGROUP overrides (tuning aid)
 static int gemm_mgroup() {
     static int v = -1;
@@ -542,7 +568,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     if (total <= 0) return GA_OK;
     if (total > (1L << 30)) return GA_ERR_ARG;
     size_t lds = NBUF * (BM + BN) * 128;
-    const size_t epi = 4 * 32 * (MI * 32 + 4) * sizeof(float);
+    const size_t epi = WM * WN * 32 * (MI * 32 + 4) * sizeof(float);
     if (lds < epi) lds = epi;
     auto kern = conv_gemm_kernel<MI, WM, WN, NBUF>;
     if (lds > 64 * 1024) {
@@ -550,7 +576,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
             return GA_ERR_LAUNCH;
     }
     const int grid = (int)((total + 7) / 8 * 8);
-    kern<<<grid, 256, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup());
+    kern<<<grid, WM * WN * 64, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup());
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
@@ -572,6 +598,11 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
         if (2 * blocks <= gemm_deep_max_blocks() && ksteps >= 6) return launch_gemm<1, 2, 2, 4>(p, s);
         return launch_gemm<1, 2, 2, 2>(p, s);
     }
+    // many tiles and >= 256 output channels: 256x128 tiles on eight waves.  The 128x128 kernel moves 32 KB into LDS per
+    // 2.1 MFLOP (64 FLOP/B) and runs at 60-75 % of the ~18 TB/s the chip's L2s deliver to direct-to-LDS gathers; the wide
+    // tile needs 48 KB per 4.2 MFLOP (85 FLOP/B)
+    if (!gemm_nbuf_override() && gemm_wide_mode() && p.M >= 256 && p.M % 256 == 0 && blocks >= gemm_wide_min_blocks())
+        return gemm_wide_mode() == 3 ? launch_gemm<2, 4, 2, 3>(p, s) : launch_gemm<2, 4, 2, 2>(p, s);
     int nbuf = gemm_nbuf_override();
     if (!nbuf) nbuf = blocks >= 600 ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
