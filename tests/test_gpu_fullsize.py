@@ -1,0 +1,113 @@
+"""GPU, at the bench workload's FULL size (B=12, T=375 latent frames, S=120000 samples, bf16): properties of the hot path that
+hold at any size and need no CPU oracle run (the oracle takes ~1 s per sample-iteration there).
+
+  * batch-item independence: G, the decoder and D act on every item separately, so the first half of a batch of 12 gives
+    the same waveforms / logits as a batch of those 6 alone (tiles straddle items and grids differ, the arithmetic per
+    output element does not);
+  * mean-loss linearity: the D step's gradient buffer for the batch of 12 is the average of the two half-batch buffers
+    (every weight-gradient, unpack and weight-norm kernel at full size, fp32 accumulation);
+  * identity: feature matching and MR-STFT between a signal and itself are exactly zero, and so are their gradients;
+  * the full iteration is finite and moves every parameter of G and D.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bench
+from gan_amd import lab3_codec_train as T
+from gan_amd.lab3_codec_models import CodecTrainWeights, multiscale_hinge_d_loss
+from gan_amd.optim import FusedAdamW
+
+DEV = torch.device("cuda")
+B, FRAMES = 12, 375
+
+
+@pytest.fixture(scope="module")
+def world():
+    G, D, codec = bench.make_models("bf16", DEV, seed=3)
+    batch = bench.make_batch(B, FRAMES, DEV, torch.Generator().manual_seed(4))
+    return G, D, codec, batch
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12))
+
+
+def test_batch_item_independence_at_full_size(world):
+    G, D, codec, (q_src, zc, zs, noise, q_real, _) = world
+    with torch.no_grad():
+        q_hat = G(q_src=q_src, z_content=zc, z_style_tgt=zs, noise=noise)
+        x_hat = codec.decode_embeddings(q_hat)
+        q_half = G(q_src=q_src[:6], z_content=zc[:6], z_style_tgt=zs[:6], noise=noise[:6])
+        x_half = codec.decode_embeddings(q_half)
+        assert x_hat.shape == (B, 1, FRAMES * 320)
+        assert rel(q_hat[:6], q_half) <= 1e-6 and rel(x_hat[:6], x_half) <= 1e-6
+        full, half = D(x_hat), D(x_hat[6:])
+        # D's deep-K layers pick their split-K factor from the grid size, so the fp32 summation order (not the terms) may
+        # differ between the two batch sizes: one bf16 rounding step (2^-8) of the largest value at most
+        for (lg, fs), (lg2, fs2) in zip(full, half):
+            assert rel(lg[6:], lg2) <= 8e-3
+            assert all(rel(a[6:], b) <= 8e-3 for a, b in zip(fs, fs2))
+
+
+def test_d_step_gradient_is_the_mean_of_half_batch_gradients(world):
+    G, D, codec, (q_src, zc, zs, noise, q_real, _) = world
+    opt_d = FusedAdamW(D.parameters(), lr=1e-4)
+    with torch.no_grad():
+        x_fake = codec.decode_embeddings(G(q_src=q_src, z_content=zc, z_style_tgt=zs, noise=noise))
+        x_real = codec.decode_embeddings(q_real)
+
+    def flat(sl):
+        opt_d.zero_grad(set_to_none=True)
+        n = x_real[sl].shape[0]
+        both = D(torch.cat([x_real[sl], x_fake[sl]], dim=0))
+        loss = multiscale_hinge_d_loss([(lg[:n], None) for lg, _ in both], [(lg[n:], None) for lg, _ in both])
+        T._backward_and_reduce(loss, opt_d, None)
+        return opt_d.flat_g.clone()
+
+    g_all, g_a, g_b = flat(slice(0, B)), flat(slice(0, 6)), flat(slice(6, B))
+    assert float(g_all.abs().max()) > 0
+    # bf16 activations differ by a rounding step between the batch sizes (split-K factors follow the grid size), which flips a
+    # few LeakyReLU / hinge masks near zero: ~1 % of the largest gradient entry; a wrong kernel would be off by O(1)
+    assert rel(0.5 * (g_a + g_b), g_all) <= 3e-2
+    cos = torch.nn.functional.cosine_similarity(0.5 * (g_a + g_b), g_all, dim=0)
+    assert float(cos) >= 0.9995
+
+
+def test_identity_losses_vanish_at_full_size(world):
+    G, D, codec, (q_src, *_rest) = world
+    with torch.no_grad():
+        x = codec.decode_embeddings(q_src)
+    for prm in D.parameters():
+        prm.requires_grad_(False)
+    try:
+        xf = x.clone().requires_grad_(True)
+        _, _, fm = D.forward_real_fake(x, xf, want_fm=True)
+        assert float(fm) == 0.0
+        fm.backward()
+        assert xf.grad is None or float(xf.grad.abs().max()) == 0.0
+    finally:
+        for prm in D.parameters():
+            prm.requires_grad_(True)
+    xp = x.clone().requires_grad_(True)
+    st = T._waveform_mrstft_loss(wav_pred=xp, wav_true=x, resolutions=T.CodecStageTrainConfig(stage_name="stage2", epochs=1).wave_mrstft_resolutions, precision="bf16")
+    assert abs(float(st)) <= 1e-6
+    st.backward()
+    assert float(xp.grad.abs().max()) <= 1e-6
+
+
+def test_full_size_iteration_is_finite_and_moves_every_parameter(world):
+    G, D, codec, batch = world
+    scfg = T.CodecStageTrainConfig(stage_name="stage2", epochs=1, d_step_period=1, g_grad_clip_norm=5.0, d_grad_clip_norm=5.0,
+                                   weights=CodecTrainWeights(content=0.0, style=0.0))
+    opt_g = FusedAdamW(G.parameters(), lr=scfg.lr_g, betas=scfg.betas)
+    opt_d = FusedAdamW(D.parameters(), lr=scfg.lr_d, betas=scfg.betas)
+    before = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    out = T.codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, *batch, global_step=1)
+    vals = {k: float(v) for k, v in out.items() if v.dim() == 0}
+    assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
+    assert vals["loss_fm"] > 0 and vals["loss_mrstft"] > 0
+    assert float(out["g_grad_norm"]) > 0 and float(out["d_grad_norm"]) > 0
+    after = list(G.parameters()) + list(D.parameters())
+    assert all(not torch.equal(a, b) for a, b in zip(after, before))
