@@ -141,6 +141,68 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(ConvParams p) {
     }
 }
 
+// thin kernel A', M == 1 and Cin % 8 == 0 with at most 256 16-byte pieces per output (D.out: 512 -> 1, k3 = 192 pieces): one wave
+// per output step like kernel A, but a lane owns fixed pieces (tap j, 8 consecutive channels), keeps their weights in
+// registers for every step it visits and fetches each with ONE 16-byte load -- no per-element division, no scalar loads.
+template <typename T> __device__ __forceinline__ void load8(const T* q, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* q, float (&v)[8]) {
+    const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* q, float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 raw_t;
+    const raw_t r = *(const raw_t*)q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_m1_wave_kernel(ConvParams p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+    const int off0 = p.off0 + p.phase_off0[phase];
+    const T* __restrict__ w = (const T*)p.w + (size_t)phase * p.J * p.Cin;
+    const T* __restrict__ x = (const T*)p.x + (size_t)b * p.Lin * p.Cin;
+    const int parts = p.Cin / 8, KP = p.J * parts;
+    float wr[4][8];
+    int dr[4], dc[4];
+    bool on[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = lane + 64 * q;
+        on[q] = piece < KP;
+        const int j = on[q] ? piece / parts : 0, part = on[q] ? piece - j * parts : 0;
+        dr[q] = j * p.tap_step;
+        dc[q] = part * 8;
+        load8<T>(w + (size_t)j * p.Cin + part * 8, wr[q]);
+    }
+    for (int t = p.t0 + blockIdx.x * 4 + wid; t < p.t0 + p.Lout; t += gridDim.x * 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int row = t * p.in_stride + dr[q] + off0;
+            if (row < 0 && p.pad_mode == 1) row = -row;
+            if (!on[q] || row < 0 || row >= p.Lin) continue;
+            float xv[8];
+            load8<T>(x + (size_t)row * p.Cin + dc[q], xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(p.pre_act ? act_apply(p.pre_act, xv[e]) : xv[e], wr[q][e], acc);
+        }
+        acc = wave_sum(acc);
+        const int orow = t * p.out_stride + phase;
+        if (lane == 0 && orow >= 0 && orow < p.LoutTot) {
+            const size_t idx = (size_t)b * p.LoutTot + orow;
+            float v = acc;
+            if (p.bias) v += p.bias[0];
+            v = act_apply(p.post_act, v);
+            if (p.dact_mode) v *= dact_apply(p.dact_mode, (float)((const T*)p.dact_src)[idx]);
+            if (p.res) v += (float)((const T*)p.res)[idx];
+            if (p.accumulate) v += (float)((T*)p.y)[idx];
+            ((T*)p.y)[idx] = (T)v;
+        }
+    }
+}
+
 // thin kernel B: one input channel (D block 0: 1 -> 32, k15).  One thread per (t, m); the J inputs
 // of a step are contiguous and shared through L1, weights sit in LDS.  HBM-bound on the output.
 template <typename T>
@@ -288,6 +350,12 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradParams p) {
     }
 }
 
+// shapes of conv_m1_wave_kernel (also consulted by the thin-kernel dispatch, which hands these over)
+int ga_conv_m1_wave_ok(const ConvParams& p, int esz) {
+    return p.M == 1 && p.Cin % 8 == 0 && p.Cin >= 128 && (long)p.J * (p.Cin / 8) <= 256 && !p.out_f32 &&
+           ((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0 && ((size_t)p.Cin * esz) % 16 == 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 static int check_conv(const ConvParams& p) {
     if (!p.x || !p.w || !p.y) return GA_ERR_ARG;
@@ -304,7 +372,10 @@ static int launch_conv_direct(const ConvParams& p, hipStream_t s) {
     if (p.M <= 4) {
         int gx = (p.Lout + 3) / 4;
         if (gx > 8192) gx = 8192;
-        conv_fewout_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, 0, s>>>(p);
+        if (ga_conv_m1_wave_ok(p, (int)sizeof(T)))
+            conv_m1_wave_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, 0, s>>>(p);
+        else
+            conv_fewout_kernel<T><<<dim3(gx, 1, p.B * p.nphase), 256, 0, s>>>(p);
     } else if (p.Cin == 1 && p.nphase == 1 && (size_t)(p.M * p.J + p.M) * 4 <= 48 * 1024) {
         size_t total = (size_t)p.Lout * p.M;
         int gx = (int)((total + 255) / 256);

@@ -506,9 +506,12 @@ static int thin_conv_t(const ConvParams& p, hipStream_t s) {
 }
 
 // returns 1 when one of the vectorised thin forward kernels applies
+int ga_conv_m1_wave_ok(const ConvParams& p, int esz);  // conv_direct.hip
+
 int ga_thin_conv_supported(const ConvParams& p, int dtype) {
     const size_t esz = dtype == GA_DTYPE_BF16 ? 2 : 4;
     if (p.M <= 4) {
+        if (ga_conv_m1_wave_ok(p, (int)esz)) return 0;  // wide single-output layers (D.out): the wave-per-step vector kernel
         if (p.Cin % 8 || (size_t)p.M * p.J * p.Cin * 4 > 48 * 1024) return 0;
         if (p.out_f32 && (p.res || p.dact_src || p.accumulate)) return 0;
         if ((long)p.Lout * p.B < 8192 && !p.out_f32) return 0;  // short problems: the wave-per-row kernel has more parallelism
@@ -553,7 +556,11 @@ __global__ __launch_bounds__(256) void wgrad_m1_wide_kernel(WgradParams p, float
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
     float gsum = 0.f;
-    for (long n0 = rl; n0 < nrows; n0 += 64 * 4) {
+    // gridDim.y slices of the row range (the per-output sums already end in atomics): 16 workgroups walking every row
+    // left the chip idle for 70 us on D's last conv
+    const long per = ((nrows + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+    const long n_lo = (long)blockIdx.y * per, n_hi = n_lo + per < nrows ? n_lo + per : nrows;
+    for (long n0 = n_lo + rl; n0 < n_hi; n0 += 64 * 4) {
         Vec8<T> xv[4];
         float gv[4][8];
 #pragma unroll
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(256) void wgrad_m1_wide_kernel(WgradParams p, float
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int t = R - j * p.tap_step - p.off0;
-                const bool ok = j < p.J && n < nrows && t >= 0 && t < p.Lout;
+                const bool ok = j < p.J && n < n_hi && t >= 0 && t < p.Lout;
                 const int tc = t < 0 ? 0 : (t >= p.Lout ? p.Lout - 1 : t);
                 const float v = (float)g[(size_t)b * p.LgTot + (size_t)tc * p.g_stride + p.g_phase];
                 gv[u][j] = ok ? v : 0.f;
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(256) void wgrad_m1_wide_kernel(WgradParams p, float
     }
     if (dbias && blockIdx.x == 0) {
         __syncthreads();
-        for (long i = threadIdx.x; i < (long)p.B * p.Lout; i += 256) {
+        for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < (long)p.B * p.Lout; i += 256L * gridDim.y) {
             const long b = i / p.Lout, t = i - b * p.Lout;
             gsum += (float)g[(size_t)b * p.LgTot + (size_t)t * p.g_stride + p.g_phase];
         }
@@ -609,7 +616,10 @@ static int thin_wgrad_t(const WgradParams& p, float* dbias, int kind, hipStream_
         wgrad_cin1_kernel<T><<<p.B * chunks_per_b, 256, 0, s>>>(p, dbias, chunks_per_b);
     } else {
         if (p.Cin >= 256 && p.Cin % 32 == 0 && p.in_stride == 1 && (long)p.B * p.Lin < (1L << 30)) {
-            wgrad_m1_wide_kernel<T><<<p.Cin / 32, 256, 0, s>>>(p, dbias);
+            long ny = ((long)p.B * p.Lin + 1023) / 1024;  // >= 4 trips of 256 rows per workgroup
+            if (ny > 32) ny = 32;
+            if (ny < 1) ny = 1;
+            wgrad_m1_wide_kernel<T><<<dim3(p.Cin / 32, (unsigned)ny), 256, 0, s>>>(p, dbias);
             GA_CHECK_LAUNCH();
             return GA_OK;
         }
