@@ -173,7 +173,15 @@ __global__ __launch_bounds__(256) void conv_fewout_lds_kernel(ConvParams p, int 
         for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
         if (R >= 0 && R < p.Lin) {
             v.load(x + (size_t)R * p.Cin + part * 8);
-            if (p.pre_act) {
+            if (p.pre_act == GA_ACT_ELU && sizeof(T) == 2) {
+                // bf16 staging: ELU(v) = v down to -2^-12 within half a bf16 step, and exp(v) - 1 below that loses nothing
+                // a bf16 keeps; expm1f's exactness near zero (the fp32 path below) costs ~50 instructions per element
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = v.v[e];
+                    v.v[e] = f > -0.000244140625f ? f : __expf(f) - 1.f;
+                }
+            } else if (p.pre_act) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] = act_apply(p.pre_act, v.v[e]);
             }
@@ -184,17 +192,35 @@ __global__ __launch_bounds__(256) void conv_fewout_lds_kernel(ConvParams p, int 
     const int t = tblk + threadIdx.x;
     if (t >= p.t0 + p.Lout) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < p.J; ++j) {
-        const T* xr = (const T*)(xs + (size_t)(threadIdx.x * p.in_stride + j * p.tap_step) * pitch);
-        const float* wj = wsm + j * p.Cin;
-        for (int c = 0; c < p.Cin; c += 8) {
-            Vec8<T> xv;
-            xv.load(xr + c);
+    if (p.M == 1) {
+        // single output channel (decoder tail, D block 0 data gradient): the 8 weights of a piece as two 16-byte broadcast
+        // reads -- with one 4-byte read per weight the LDS instruction stream, not memory, set the pace
+        for (int j = 0; j < p.J; ++j) {
+            const T* xr = (const T*)(xs + (size_t)(threadIdx.x * p.in_stride + j * p.tap_step) * pitch);
+            const float* wj = wsm + j * p.Cin;
+            for (int c = 0; c < p.Cin; c += 8) {
+                Vec8<T> xv;
+                xv.load(xr + c);
+                const float4 w0 = *(const float4*)(wj + c), w1 = *(const float4*)(wj + c + 4);
+                acc[0] = fmaf(xv.v[0], w0.x, acc[0]); acc[0] = fmaf(xv.v[1], w0.y, acc[0]);
+                acc[0] = fmaf(xv.v[2], w0.z, acc[0]); acc[0] = fmaf(xv.v[3], w0.w, acc[0]);
+                acc[0] = fmaf(xv.v[4], w1.x, acc[0]); acc[0] = fmaf(xv.v[5], w1.y, acc[0]);
+                acc[0] = fmaf(xv.v[6], w1.z, acc[0]); acc[0] = fmaf(xv.v[7], w1.w, acc[0]);
+            }
+        }
+    } else {
+        for (int j = 0; j < p.J; ++j) {
+            const T* xr = (const T*)(xs + (size_t)(threadIdx.x * p.in_stride + j * p.tap_step) * pitch);
+            const float* wj = wsm + j * p.Cin;
+            for (int c = 0; c < p.Cin; c += 8) {
+                Vec8<T> xv;
+                xv.load(xr + c);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < p.M) {
+                for (int m = 0; m < 4; ++m) {
+                    if (m < p.M) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[m] = fmaf(xv.v[e], wj[m * KC + c + e], acc[m]);
+                        for (int e = 0; e < 8; ++e) acc[m] = fmaf(xv.v[e], wj[m * KC + c + e], acc[m]);
+                    }
                 }
             }
         }
