@@ -295,6 +295,15 @@ def multiscale_hinge_d_loss(real_outs, fake_outs) -> torch.Tensor:
     return torch.stack(terms).sum() / max(1, len(real_outs))
 
 
+def multiscale_hinge_d_loss_joined(both_outs, b0: int) -> torch.Tensor:
+    """multiscale_hinge_d_loss for the joined [real ; fake] D pass: `both_outs` as returned by the discriminator on the
+    concatenated batch, whose first b0 items are the real ones."""
+    if not 0 < b0 < int(both_outs[0][0].shape[0]):
+        raise ValueError("b0 must split the batch into a real and a fake part")
+    terms = [ops.HingeDJoined.apply(lg, int(b0)) for lg, _ in both_outs]
+    return torch.stack(terms).sum() / max(1, len(both_outs))
+
+
 def multiscale_hinge_g_loss(fake_outs) -> torch.Tensor:
     terms = [hinge_g_loss(fake_logits) for fake_logits, _ in fake_outs]
     return torch.stack(terms).sum() / max(1, len(fake_outs))

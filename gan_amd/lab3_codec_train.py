@@ -24,7 +24,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .lab3_codec_models import (CodecLatentTranslator, CodecTrainWeights, MultiScaleWaveDiscriminator,
-                                multiscale_feature_matching_loss, multiscale_hinge_d_loss, multiscale_hinge_g_loss)
+                                multiscale_feature_matching_loss, multiscale_hinge_d_loss, multiscale_hinge_d_loss_joined,
+                                multiscale_hinge_g_loss)
 from .optim import FusedAdamW
 
 
@@ -154,7 +155,7 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
     x = wav_pred.squeeze(1)
     y = wav_true.squeeze(1).detach()
     B, S = x.shape
-    total = torch.zeros((), device=x.device)
+    total = None
     used = 0
     for n_fft, hop, win in resolutions:
         n_fft, hop, win = int(n_fft), int(hop), int(win)
@@ -164,9 +165,10 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
         count = float(B * (n_fft // 2 + 1) * (1 + S // hop))
         if sum_hook is not None:
             sums, count = sum_hook(sums, count)
-        sc = _safe_sqrt(sums[0]) / (_safe_sqrt(sums[1]) + 1e-8)
-        lm = sums[2] / count
-        total = total + sc + lm
+        s_diff, s_true, s_log = sums.unbind(0)  # one backward node (a stack) instead of three selects with a zero-fill each
+        sc = _safe_sqrt(s_diff) / (_safe_sqrt(s_true) + 1e-8)
+        lm = s_log / count
+        total = sc + lm if total is None else total + sc + lm
         used += 1
     if used == 0:
         return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF, 1.0 / wav_pred.numel())
@@ -199,9 +201,10 @@ def latent_losses(q_hat: torch.Tensor, q_src: torch.Tensor, delta_budget: float)
     qh = q_hat.permute(0, 2, 1)
     qs = q_src.permute(0, 2, 1).to(qh.dtype)
     sums = ops.LatentSums.apply(qh, qs)
-    l1 = sums[0] / float(B * Cn * T)
-    cont = sums[1] / float(B * Cn * max(T - 1, 1))
-    delta_mean = sums[2:] / float(Cn * T)
+    s_l1, s_cont, s_items = torch.split(sums, [1, 1, B])  # one backward node (a cat) instead of select / slice zero-fills
+    l1 = s_l1.squeeze(0) / float(B * Cn * T)
+    cont = s_cont.squeeze(0) / float(B * Cn * max(T - 1, 1))
+    delta_mean = s_items / float(Cn * T)
     budget = F.relu(delta_mean - float(delta_budget)).mean()
     return l1, cont, budget
 
@@ -276,9 +279,9 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
             # D acts on every batch item independently, so the real and fake passes (:423-424) run as ONE pass over
             # the concatenated batch: twice the GEMM N per launch, half the launches, one weight-gradient pass.
             both = discriminator(torch.cat([x_real_d_all.detach(), x_hat.detach()], dim=0))
-            real_outs = [(lg[:B0], [f[:B0] for f in fs]) for lg, fs in both]
-            fake_outs_d = [(lg[B0:], [f[B0:] for f in fs]) for lg, fs in both]
-        loss_d = multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d)
+            real_outs = fake_outs_d = None
+        loss_d = (multiscale_hinge_d_loss(real_outs=real_outs, fake_outs=fake_outs_d) if do_r1
+                  else multiscale_hinge_d_loss_joined(both, B0))
         opt_d.zero_grad(set_to_none=True)
         loss_d_total = loss_d.detach()
         if do_r1:

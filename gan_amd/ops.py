@@ -977,6 +977,41 @@ class ReduceSum(torch.autograd.Function):
         return ga, gb, None, None
 
 
+class HingeDJoined(torch.autograd.Function):
+    """mean(relu(1 - logits[:b0])) + mean(relu(1 + logits[b0:])) for a logits tensor whose batch is [real ; fake]
+    (reference hinge_d_loss, lab3_codec_models.py:171-174, on the joined D pass).  One node and one gradient buffer for both
+    halves: slicing the logits first would cost a zero-fill, a copy and an add per half in autograd's slice backward."""
+
+    @staticmethod
+    def forward(ctx, logits, b0: int):
+        L.require_cuda(logits)
+        lf, perm = _flat_view(logits)
+        per = lf[0].numel()
+        n_r, n_f = b0 * per, (lf.shape[0] - b0) * per
+        out = zeros_f32(1, lf.device)
+        esz = lf.element_size()
+        lib = L.lib()
+        L.check(lib.ga_reduce(lf.data_ptr(), None, L.dt(lf), n_r, L.RED_RELU1M, 1.0 / n_r, out.data_ptr(), L.stream()), "ga_reduce")
+        L.check(lib.ga_reduce(lf.data_ptr() + n_r * esz, None, L.dt(lf), n_f, L.RED_RELU1P, 1.0 / n_f, out.data_ptr(), L.stream()),
+                "ga_reduce")
+        ctx.save_for_backward(lf)
+        ctx.n_r, ctx.n_f, ctx.perm = n_r, n_f, perm
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        lf, = ctx.saved_tensors
+        ga = torch.empty_like(lf)
+        gout = gout.contiguous().float()
+        esz = lf.element_size()
+        lib = L.lib()
+        L.check(lib.ga_reduce_grad(lf.data_ptr(), None, L.dt(lf), ctx.n_r, L.RED_RELU1M, gout.data_ptr(), 1.0 / ctx.n_r,
+                                   ga.data_ptr(), 0, L.stream()), "ga_reduce_grad")
+        L.check(lib.ga_reduce_grad(lf.data_ptr() + ctx.n_r * esz, None, L.dt(lf), ctx.n_f, L.RED_RELU1P, gout.data_ptr(),
+                                   1.0 / ctx.n_f, ga.data_ptr() + ctx.n_r * esz, 0, L.stream()), "ga_reduce_grad")
+        return (ga.permute(0, 2, 1) if ctx.perm else ga), None
+
+
 def reduce_sum(a: Tensor, b: Optional[Tensor], op: int, scale: float = 1.0) -> Tensor:
     """scale * sum_i f(a_i, b_i) as a 0-dim fp32 tensor (the scale -- typically 1/numel -- is applied inside the kernel)."""
     return ReduceSum.apply(a, b, op, scale)
