@@ -108,6 +108,7 @@ _SIGNATURES = {
     "ga_latent_loss_fwd": [_P, _P, _I, _I, _I, _I, _P, _P],
     "ga_latent_loss_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "ga_stft_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_stft_combine": [_P, _P, _I, _P, _P, _P, _P],
     "ga_stft_loss_fwd": [_P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_stft_loss_bwd": [_P, _P, _I, _Z, _I, _I, _P, _P, _P],
     "ga_stft_unpad_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -155,6 +155,38 @@ int ga_stft_loss_bwd(const void* sx, const void* sy, int dtype, size_t frames, i
     return GA_OK;
 }
 
+// loss = (1/R) sum_r [ sqrt(s_r0) / (sqrt(s_r1) + 1e-8) + s_r2 * inv_count_r ] from the R x 3 sums of the resolutions, and its
+// gradient: ~90 one-element torch kernels (sqrt / where / div / add, forward and backward) as two launches.
+// sqrt of a non-positive sum is taken as 0 with zero derivative (the torch expression it replaces did the same).
+__global__ void stft_combine_kernel(const float* __restrict__ sums, const float* __restrict__ inv_count, int R,
+                                    const float* __restrict__ gout, float* __restrict__ out, float* __restrict__ dsums) {
+    const int r = threadIdx.x;
+    float term = 0.f;
+    if (r < R) {
+        const float s0 = sums[3 * r], s1 = sums[3 * r + 1], s2 = sums[3 * r + 2];
+        const float r0 = s0 > 0.f ? sqrtf(s0) : 0.f, r1 = s1 > 0.f ? sqrtf(s1) : 0.f;
+        const float den = r1 + 1e-8f;
+        term = r0 / den + s2 * inv_count[r];
+        if (dsums) {
+            const float g = gout[0] / (float)R;
+            dsums[3 * r] = s0 > 0.f ? g * 0.5f / (r0 * den) : 0.f;
+            dsums[3 * r + 1] = s1 > 0.f ? -g * r0 / (den * den) * 0.5f / r1 : 0.f;
+            dsums[3 * r + 2] = g * inv_count[r];
+        }
+    }
+    if (out) {
+        term = wave_sum(term);
+        if (threadIdx.x == 0) out[0] = term / (float)R;
+    }
+}
+
+int ga_stft_combine(const float* sums, const float* inv_count, int R, const float* gout, float* out, float* dsums, hipStream_t s) {
+    if (!sums || !inv_count || R < 1 || R > 64 || (!out && !dsums) || (dsums && !gout)) return GA_ERR_ARG;
+    stft_combine_kernel<<<1, 64, 0, s>>>(sums, inv_count, R, gout, out, dsums);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
 int ga_stft_unpad_bwd(const void* dxp, void* dx, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows,
                       int accumulate, hipStream_t s) {
     if (!dxp || !dx || B <= 0 || S <= 0) return GA_ERR_ARG;

@@ -224,7 +224,7 @@ class MultiScaleWaveDiscriminator(nn.Module):
             raise ValueError(f"expected wav [B, 1, S], got {tuple(wav.shape)}")
         outs: List[Tuple[torch.Tensor, List[torch.Tensor]]] = []
         ops.prepack_layers(self._pack_layers(), dtype)
-        x = wav[:, 0, :].to(dtype)  # [B, S]; with C == 1 the NLC and NCL layouts coincide
+        x = wav.squeeze(1).to(dtype)  # [B, S] (a view: no select backward); with C == 1 the NLC and NCL layouts coincide
         for i, d in enumerate(self.discs):
             if i > 0:
                 x = ops.AvgPool4s2.apply(x)
@@ -252,8 +252,8 @@ class MultiScaleWaveDiscriminator(nn.Module):
         if wav_real.shape[2] != wav_fake.shape[2]:
             raise ValueError("real and fake waveforms differ in length")
         ops.prepack_layers(self._pack_layers(), dtype)
-        xr = wav_real.detach()[:, 0, :].to(dtype)
-        xf = wav_fake[:, 0, :].to(dtype)
+        xr = wav_real.detach().squeeze(1).to(dtype)
+        xf = wav_fake.squeeze(1).to(dtype)
         real_outs, fake_outs, fm_terms = [], [], []
         for i, d in enumerate(self.discs):
             if i > 0:

@@ -140,11 +140,6 @@ def _mix_style_condition(target_idx: torch.Tensor, cond_mode: str, alpha: float,
 
 
 # ------------------------------------------------------------------------------------------------
-def _safe_sqrt(s: torch.Tensor) -> torch.Tensor:
-    pos = s > 0
-    return torch.where(pos, s, torch.ones_like(s)).sqrt() * pos
-
-
 def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolutions: Iterable[Tuple[int, int, int]],
                           sum_hook=None, precision: str = "fp32") -> torch.Tensor:
     """reference :148-176.  Per resolution one fused pass yields [sum (my-mx)^2, sum my^2, sum |log mx - log my|];
@@ -155,8 +150,7 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
     x = wav_pred.squeeze(1)
     y = wav_true.squeeze(1).detach()
     B, S = x.shape
-    total = None
-    used = 0
+    per_res, inv_counts = [], []
     for n_fft, hop, win in resolutions:
         n_fft, hop, win = int(n_fft), int(hop), int(win)
         if S < n_fft:
@@ -165,14 +159,13 @@ def _waveform_mrstft_loss(wav_pred: torch.Tensor, wav_true: torch.Tensor, resolu
         count = float(B * (n_fft // 2 + 1) * (1 + S // hop))
         if sum_hook is not None:
             sums, count = sum_hook(sums, count)
-        s_diff, s_true, s_log = sums.unbind(0)  # one backward node (a stack) instead of three selects with a zero-fill each
-        sc = _safe_sqrt(s_diff) / (_safe_sqrt(s_true) + 1e-8)
-        lm = s_log / count
-        total = sc + lm if total is None else total + sc + lm
-        used += 1
-    if used == 0:
-        return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF, 1.0 / wav_pred.numel())
-    return total / float(used)
+        per_res.append(sums)
+        inv_counts.append(1.0 / count)
+    used = len(per_res)
+    if used:
+        # sc + lm of every resolution and their mean in one launch (and one back)
+        return ops.StftCombine.apply(torch.stack(per_res), ops.const_vec(inv_counts, x.device))
+    return ops.reduce_sum(wav_pred, wav_true.detach(), L.RED_ABSDIFF, 1.0 / wav_pred.numel())  # signal shorter than every n_fft
 
 
 # ------------------------------------------------------------------------------------------------
@@ -348,11 +341,15 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         den = torch.mean(torch.abs(noise - noise2)).clamp_min(1e-5)
         loss_ms = F.relu(float(stage_cfg.mode_seeking_target) - num / den)
 
-    loss_g = (float(w.adv) * loss_adv + float(w.feature_match) * loss_fm + float(w.latent_l1) * loss_lat_l1
-              + float(w.latent_continuity) * loss_lat_cont + float(w.mrstft) * loss_mrstft
-              + float(w.mode_seeking) * loss_ms + float(w.delta_budget) * loss_delta_budget)
+    terms = [loss_adv, loss_fm, loss_lat_l1, loss_lat_cont, loss_mrstft, loss_delta_budget]
+    wts = [w.adv, w.feature_match, w.latent_l1, w.latent_continuity, w.mrstft, w.delta_budget]
+    if float(w.mode_seeking) > 0.0:
+        terms.append(loss_ms)
+        wts.append(w.mode_seeking)
     if style_judge is not None:
-        loss_g = loss_g + float(w.style) * loss_style + float(w.style_push) * loss_style_push
+        terms += [loss_style, loss_style_push]
+        wts += [w.style, w.style_push]
+    loss_g = ops.weighted_sum(terms, wts)
     opt_g.zero_grad(set_to_none=True)
     opt_g.max_grad_norm = float(stage_cfg.g_grad_clip_norm)
     _backward_and_reduce(loss_g, opt_g, dp)

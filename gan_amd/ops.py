@@ -977,6 +977,50 @@ class ReduceSum(torch.autograd.Function):
         return ga, gb, None, None
 
 
+class StftCombine(torch.autograd.Function):
+    """(1/R) sum_r [ sqrt(s_r0) / (sqrt(s_r1) + 1e-8) + s_r2 / count_r ] of the stacked per-resolution sums [R, 3]
+    (spectral convergence + log-magnitude L1, reference lab3_codec_train.py:161-176) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, sums, inv_count):
+        sums = sums.contiguous().float()
+        out = torch.empty((1,), device=sums.device, dtype=torch.float32)
+        L.check(L.lib().ga_stft_combine(sums.data_ptr(), inv_count.data_ptr(), sums.shape[0], None, out.data_ptr(), None, L.stream()),
+                "ga_stft_combine")
+        ctx.save_for_backward(sums, inv_count)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        sums, inv_count = ctx.saved_tensors
+        ds = torch.empty_like(sums)
+        gout = gout.reshape(1).float().contiguous()
+        L.check(L.lib().ga_stft_combine(sums.data_ptr(), inv_count.data_ptr(), sums.shape[0], gout.data_ptr(), None, ds.data_ptr(),
+                                        L.stream()), "ga_stft_combine")
+        return ds, None
+
+
+_CONST_VECS: dict = {}
+
+
+def const_vec(values, device) -> Tensor:
+    """A cached fp32 device vector of Python floats (loss weights, reciprocal counts): built once per distinct tuple."""
+    key = (torch.device(device), tuple(float(v) for v in values))
+    t = _CONST_VECS.get(key)
+    if t is None:
+        if len(_CONST_VECS) > 256:
+            _CONST_VECS.clear()
+        t = _CONST_VECS[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+    return t
+
+
+def weighted_sum(terms, weights) -> Tensor:
+    """sum_i weights[i] * terms[i] for 0-dim device tensors: one stack, one multiply, one sum (and two kernels back)
+    instead of a multiply and an add per term each way."""
+    st = torch.stack([t.reshape(()) for t in terms])
+    return (st * const_vec(weights, st.device)).sum()
+
+
 class HingeDJoined(torch.autograd.Function):
     """mean(relu(1 - logits[:b0])) + mean(relu(1 + logits[b0:])) for a logits tensor whose batch is [real ; fake]
     (reference hinge_d_loss, lab3_codec_models.py:171-174, on the joined D pass).  One node and one gradient buffer for both

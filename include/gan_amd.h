@@ -265,6 +265,10 @@ int ga_stft_loss_fwd(const void* spec_x, const void* spec_y, int dtype, size_t f
                      ga_stream_t stream);
 int ga_stft_loss_bwd(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec,
                      const float* coef, void* dspec_x, ga_stream_t stream);
+/* MR-STFT scalar tail (lab3_codec_train.py:161-176): out[0] = (1/R) sum_r [ sqrt(sums[r][0]) / (sqrt(sums[r][1]) + 1e-8)
+ * + sums[r][2] * inv_count[r] ] (out != NULL) and/or dsums = gout[0] * d out / d sums (dsums != NULL).  R <= 64. */
+int ga_stft_combine(const float* sums, const float* inv_count, int R, const float* gout, float* out, float* dsums,
+                    ga_stream_t stream);
 int ga_stft_unpad_bwd(const void* dxp, void* dx, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows,
                       int accumulate, ga_stream_t stream);
 
