@@ -542,6 +542,18 @@ static int gemm_wide_min_blocks() {
     return v;
 }
 
+// grids of at least this many 128x128 workgroups take the single-buffer kernel (four workgroups per CU); GA_GEMM_NBUF1_MIN
+// overrides (tuning aid)
+static int gemm_single_min_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_GEMM_NBUF1_MIN");
+        v = e ? atoi(e) : 450;  // swept 300 / 450 / 600 / 800 / 1100 at four workgroups per CU: 450 is the best by 1.7 % of GEMM time
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 // m-tiles per group in the tile order (see the kernel); GA_GEMM_MGROUP overrides (tuning aid)
 static int gemm_mgroup() {
     static int v = -1;
@@ -604,6 +616,6 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!gemm_nbuf_override() && gemm_wide_mode() && p.M >= 256 && p.M % 256 == 0 && blocks >= gemm_wide_min_blocks())
         return gemm_wide_mode() == 3 ? launch_gemm<2, 4, 2, 3>(p, s) : launch_gemm<2, 4, 2, 2>(p, s);
     int nbuf = gemm_nbuf_override();
-    if (!nbuf) nbuf = blocks >= 600 ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
+    if (!nbuf) nbuf = blocks >= gemm_single_min_blocks() ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
 }
