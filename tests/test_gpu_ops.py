@@ -493,6 +493,54 @@ def test_deferred_weight_gradients_match_per_layer_path(preset_grad):
         ops.WGRAD_SINK = True
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_joined_hinge_and_scalar_loss_tails(dtype):
+    """ops.HingeDJoined against hinge_d_loss on the two slices (value and gradient, unequal halves, NCL view of an NLC
+    buffer); ops.StftCombine against the torch expression it replaces, including a zero sum (sqrt(0) := 0 with zero
+    derivative); ops.weighted_sum against the plain weighted sum."""
+    from gan_amd import lab3_codec_models as M
+    torch.manual_seed(91)
+    base = (1.5 * torch.randn(5, 301, 1, device=DEV)).to(dtype)
+    for b0 in (2, 3):
+        a = base.clone().requires_grad_(True)
+        lg = a.permute(0, 2, 1)  # [B, 1, L] view, as the discriminator returns its logits
+        ref = M.hinge_d_loss(lg[:b0], lg[b0:])
+        ref.backward()
+        b = base.clone().requires_grad_(True)
+        got = ops.HingeDJoined.apply(b.permute(0, 2, 1), b0)
+        got.backward()
+        assert float(got) == pytest.approx(float(ref), rel=1e-6)
+        close(b.grad.float().cpu(), a.grad.float().cpu(), 1e-6, f"joined hinge gradient (b0={b0})")
+    sums = torch.tensor([[4.0, 9.0, 50.0], [0.0, 2.5, 7.0], [3.0, 0.0, 1.0]], device=DEV, requires_grad=True)
+    inv = [1.0 / 100.0, 1.0 / 7.0, 0.5]
+
+    def torch_tail(sm):
+        tot = 0.0
+        for r in range(sm.shape[0]):
+            s0, s1, s2 = sm[r, 0], sm[r, 1], sm[r, 2]
+            r0 = torch.where(s0 > 0, s0, torch.ones_like(s0)).sqrt() * (s0 > 0)
+            r1 = torch.where(s1 > 0, s1, torch.ones_like(s1)).sqrt() * (s1 > 0)
+            tot = tot + r0 / (r1 + 1e-8) + s2 * inv[r]
+        return tot / float(sm.shape[0])
+
+    ref = torch_tail(sums[:2])  # rows with a positive denominator: same value and gradient
+    sm2 = sums.detach()[:2].clone().requires_grad_(True)
+    got = ops.StftCombine.apply(sm2, ops.const_vec(inv[:2], DEV))
+    g_ref, = torch.autograd.grad(ref, sums)
+    g_got, = torch.autograd.grad(got, sm2)
+    assert float(got) == pytest.approx(float(ref), rel=1e-6)
+    close(g_got.cpu(), g_ref[:2].cpu(), 1e-5, "stft tail gradient")
+    sm3 = sums.detach().clone().requires_grad_(True)  # third row: zero denominator sum -> r0 / 1e-8, finite, zero d/ds1
+    got3 = ops.StftCombine.apply(sm3, ops.const_vec(inv, DEV))
+    g3, = torch.autograd.grad(got3, sm3)
+    assert torch.isfinite(got3) and torch.isfinite(g3).all() and float(g3[2, 1]) == 0.0 and float(g3[1, 0]) == 0.0
+    terms = [torch.tensor(v, device=DEV, requires_grad=True) for v in (0.3, -1.25, 4.0)]
+    ws = ops.weighted_sum(terms, [2.0, 0.5, 0.0])
+    ws.backward()
+    assert float(ws) == pytest.approx(0.6 - 0.625, rel=1e-6)
+    assert [float(t.grad) for t in terms] == [2.0, 0.5, 0.0]
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
