@@ -93,6 +93,7 @@ _SIGNATURES = {
     "ga_unpack_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_wn_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "ga_gn_stats": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ga_gn_film_act_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ga_gn_film_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ga_gn_film_act_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ga_tanh_residual_fwd": [_P, _P, _P, _I, _Z, _F, _P],

@@ -532,7 +532,12 @@ __global__ __launch_bounds__(256) void gn_film_act_bwd_kernel(const T* __restric
 #define GN_MAXR 8
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* __restrict__ x, int Tn, int C, int G, float eps,
-                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma = nullptr,
+                                                            const float* __restrict__ beta = nullptr,
+                                                            const float* __restrict__ ab = nullptr,
+                                                            const T* __restrict__ res = nullptr, T* __restrict__ y = nullptr,
+                                                            int act = 0) {
     constexpr int EV = 16 / sizeof(T);
     __shared__ float red[16];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
@@ -579,10 +584,40 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(const T* __restrict__
             for (int e = 0; e < EV; ++e) { const float d = (float)v.v[e] - mu; q = fmaf(d, d, q); }
         }
     q = block_sum(q, red) / n;
+    const float rs = rsqrtf(q + eps);
     if (tid == 0) {
         mean[blockIdx.x] = mu;
-        rstd[blockIdx.x] = rsqrtf(q + eps);
+        rstd[blockIdx.x] = rs;
     }
+    if (!y || !active) return;
+    // fused forward (ga_gn_film_act_fused): normalise, FiLM, activation (+ residual) on the rows still in registers
+    const int c0 = g * cg + part * EV;
+    float gm[EV], bt[EV], fa[EV], fb[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+        gm[e] = gamma[c0 + e];
+        bt[e] = beta[c0 + e];
+        fa[e] = ab ? 1.f + ab[(size_t)b * 2 * C + c0 + e] : 1.f;
+        fb[e] = ab ? ab[(size_t)b * 2 * C + C + c0 + e] : 0.f;
+    }
+    const size_t base = (size_t)b * Tn * C + c0;
+    auto emit = [&](const Pack16<T>& vx, int t) __attribute__((always_inline)) {
+        Pack16<T> o, r;
+        if (res) r = *(const Pack16<T>*)(res + base + (size_t)t * C);
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            float v = ((float)vx.v[e] - mu) * rs * gm[e] + bt[e];  // the same expression, in the same order, as the two-launch path
+            if (ab) v = v * fa[e] + fb[e];
+            v = act_apply(act, v);
+            if (res) v += (float)r.v[e];
+            o.v[e] = (T)v;
+        }
+        *(Pack16<T>*)(y + base + (size_t)t * C) = o;
+    };
+#pragma unroll
+    for (int k = 0; k < GN_MAXR; ++k)
+        if (r0 + k * rpp < Tn) emit(cache[k], r0 + k * rpp);
+    for (int t = r0 + GN_MAXR * rpp; t < Tn; t += rpp) emit(*(const Pack16<T>*)(xb + (size_t)t * C), t);
 }
 
 template <typename T>
@@ -1088,6 +1123,21 @@ int ga_gn_stats(const void* x, int dtype, int B, int T, int C, int G, float eps,
         DISPATCH_T(dtype, (gn_stats_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd)),
                    (gn_stats_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd)));
     }
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_gn_film_act_fused(const void* x, const float* gamma, const float* beta, const float* ab, const void* res, void* y,
+                         float* mean, float* rstd, int dtype, int B, int T, int C, int G, float eps, int act, hipStream_t s) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || T <= 0 || C <= 0 || G <= 0 || C % G) return GA_ERR_ARG;
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    const int cg = C / G;
+    const bool vec = cg % ev == 0 && cg / ev <= 256 && C % ev == 0 &&
+                     (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0;
+    if (!vec) return GA_ERR_UNSUPPORTED;
+    DISPATCH_T(dtype,
+               (gn_stats_vec_kernel<float><<<B * G, 256, 0, s>>>((const float*)x, T, C, G, eps, mean, rstd, gamma, beta, ab, (const float*)res, (float*)y, act)),
+               (gn_stats_vec_kernel<bf16_t><<<B * G, 256, 0, s>>>((const bf16_t*)x, T, C, G, eps, mean, rstd, gamma, beta, ab, (const bf16_t*)res, (bf16_t*)y, act)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -844,6 +844,9 @@ class ConvFrozen(torch.autograd.Function):
 
 
 # ================================================================================================
+GN_FUSED = True  # tests switch this off to compare against the two-launch path
+
+
 class GnFilmAct(torch.autograd.Function):
     """GroupNorm(G) -> FiLM (x*(1+a)+b) -> act (+ residual): lab3_codec_models.py:20-25,38-47,114-115."""
 
@@ -854,16 +857,21 @@ class GnFilmAct(torch.autograd.Function):
         mean = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib = L.lib()
-        L.check(lib.ga_gn_stats(x.data_ptr(), L.dt(x), B, T, Cn, groups, eps, mean.data_ptr(), rstd.data_ptr(), L.stream()), "ga_gn_stats")
         y = torch.empty_like(x)
         if ab is not None:
             ab = ab.contiguous()
             assert ab.dtype == torch.float32 and tuple(ab.shape) == (B, 2 * Cn)
         if res is not None:
             res = res.contiguous()
-        L.check(lib.ga_gn_film_act_fwd(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                       L.ptr(ab), L.ptr(res), y.data_ptr(), L.dt(x), B, T, Cn, groups, act, L.stream()),
-                "ga_gn_film_act_fwd")
+        rc = lib.ga_gn_film_act_fused(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), L.ptr(ab), L.ptr(res), y.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), L.dt(x), B, T, Cn, groups, eps, act, L.stream()) if GN_FUSED else 4
+        if rc == 4:  # GA_ERR_UNSUPPORTED: statistics and the normalise/FiLM/activation pass as two launches
+            L.check(lib.ga_gn_stats(x.data_ptr(), L.dt(x), B, T, Cn, groups, eps, mean.data_ptr(), rstd.data_ptr(), L.stream()), "ga_gn_stats")
+            L.check(lib.ga_gn_film_act_fwd(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           L.ptr(ab), L.ptr(res), y.data_ptr(), L.dt(x), B, T, Cn, groups, act, L.stream()),
+                    "ga_gn_film_act_fwd")
+        else:
+            L.check(rc, "ga_gn_film_act_fused")
         ctx.save_for_backward(x, mean, rstd, gamma, beta, ab)
         ctx.groups, ctx.act, ctx.has_res = groups, act, res is not None
         return y

@@ -541,6 +541,28 @@ def test_joined_hinge_and_scalar_loss_tails(dtype):
     assert [float(t.grad) for t in terms] == [2.0, 0.5, 0.0]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_groupnorm_forward_matches_two_launch_path(dtype):
+    """ga_gn_film_act_fused (statistics + normalise + FiLM + SiLU + residual in one launch) against ga_gn_stats followed by
+    ga_gn_film_act_fwd: outputs and the saved statistics, bit for bit (same expression order), with and without FiLM /
+    residual, a slab longer than the register cache (T = 2100) and one shorter than a pass (T = 5)."""
+    torch.manual_seed(17)
+    for (B, T, Cn, G) in ((3, 375, 256, 8), (2, 2100, 64, 8), (2, 5, 128, 8)):
+        x = (torch.randn(B, T, Cn, device=DEV) * 1.7 + 0.3).to(dtype)
+        gamma, beta = torch.randn(Cn, device=DEV), torch.randn(Cn, device=DEV)
+        for with_ab, with_res in ((True, True), (False, False), (True, False)):
+            ab = 0.3 * torch.randn(B, 2 * Cn, device=DEV) if with_ab else None
+            res = torch.randn(B, T, Cn, device=DEV).to(dtype) if with_res else None
+            outs = []
+            for fused in (True, False):
+                ops.GN_FUSED = fused
+                try:
+                    outs.append(ops.GnFilmAct.apply(x, gamma, beta, ab, res, G, L.ACT_SILU, 1e-5))
+                finally:
+                    ops.GN_FUSED = True
+            assert torch.equal(outs[0], outs[1]), (B, T, Cn, with_ab, with_res)
+
+
 def test_folded_phases_match_phase_by_phase():
     """Strided-conv data gradients and transposed-conv forwards with their output phases folded into the channel dimension
     (one GEMM over rows of S*M channels) against the S phase-by-phase launches, including item lengths that are not a
