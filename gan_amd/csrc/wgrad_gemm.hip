@@ -14,6 +14,7 @@
 //   transposing read touches land on different bank quarters (conflict-free); the XOR sits on the SOURCE piece.
 //   The reduction range is split over gridDim.y; partial tiles are added with fp32 atomics (128-byte row segments).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -208,6 +209,17 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
     }
 }
 
+// GA_WGRAD_TARGET overrides the number of workgroups a launch aims for (tuning aid)
+static long wgg_target_blocks() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_WGRAD_TARGET");
+        v = e ? atol(e) : 768;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles) {
     const int Ktot = p.J * p.Cin + (p.dbias ? 8 : 0);  // (+ one 16-byte piece for the bias column)
     const long Ntot = (long)p.B * p.Lout;
@@ -215,7 +227,7 @@ static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, l
     ktiles = (Ktot + 127) / 128;
     base = (long)mtiles * ktiles;
     nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
-    splits = (768 + base - 1) / base;               // aim for ~3 workgroups per CU
+    splits = (wgg_target_blocks() + base - 1) / base;  // workgroups aimed for (two are resident per CU: 64 KB of LDS each)
     const long max_splits = (nsteps + 7) / 8;       // at least 8 steps (512 rows) per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
