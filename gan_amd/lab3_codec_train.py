@@ -203,8 +203,9 @@ def latent_losses(q_hat: torch.Tensor, q_src: torch.Tensor, delta_budget: float)
 
 
 def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
-    """loss.backward() with the gradients landing in opt.flat_g; under data parallelism the buckets of the flat buffer are
-    all-reduced while the backward pass is still producing the earlier layers' gradients (gan_amd/dp.py)."""
+    """loss.backward() with the gradients landing in opt.flat_g (the conv weights' through ops.WeightGradSink: one launch per
+    module instead of unpack / weight-norm backward / copy per layer).  Under data parallelism the flat buffer is then
+    all-reduced in buckets; with dp.overlap the buckets go out while the backward pass is still running (gan_amd/dp.py)."""
     if dp is not None and getattr(dp, "overlap", False):
         dp.begin_backward(opt)
         loss.backward()

@@ -207,7 +207,8 @@ int ga_wn_bwd(const float* dw, const float* v, const float* g, const float* norm
 /* GroupNorm(8) -> FiLM -> SiLU (+ residual): lab3_codec_models.py:20-25,33-47,85,114-115
  *   y = act(((x-mean)*rstd*gamma+beta)*(1+a[b,c]) + bb[b,c]) + res;  ab = [B][2C] = (a | bb) or NULL (no FiLM) */
 int ga_gn_stats(const void* x, int dtype, int B, int T, int C, int G, float eps, float* mean, float* rstd, ga_stream_t stream);
-/* ga_gn_stats + ga_gn_film_act_fwd in one launch (a (b, group) slab is normalised from the registers its statistics were
+/* ga_gn_stats + ga_gn_film_act_fwd in one launch: GroupNorm(8) -> FiLM -> SiLU (+ residual) of lab3_codec_models.py:20-25,38-47,
+ * 114-115 and lab3_codec_judge.py:98-108 (a (b, group) slab is normalised from the registers its statistics were
  * taken from); mean / rstd are still written for the backward pass.  GA_ERR_UNSUPPORTED when C/G is not a multiple of the
  * 16-byte vector width or a pointer is not 16-byte aligned: call the two entry points instead. */
 int ga_gn_film_act_fused(const void* x, const float* gamma, const float* beta, const float* ab, const void* res, void* y,
