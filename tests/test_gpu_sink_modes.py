@@ -1,0 +1,54 @@
+"""GPU: a full iteration with mode seeking (the generator runs twice, so every G weight receives two gradient contributions)
+and R1 (gradients already in p.grad before the hinge backward) gives the same updated parameters with the deferred
+weight-gradient path (ops.WeightGradSink) as with plain per-layer autograd."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gan_amd import lab3_codec_train as T
+from gan_amd import ops
+from gan_amd.lab3_codec_bridge import FrozenEncodec
+from gan_amd.lab3_codec_models import CodecLatentTranslator, CodecTrainWeights, MultiScaleWaveDiscriminator
+from gan_amd.optim import FusedAdamW
+
+DEV = torch.device("cuda")
+
+
+def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
+    torch.manual_seed(44)
+    G0 = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="fp32").to(DEV).train()
+    D0 = MultiScaleWaveDiscriminator(2, precision="fp32").to(DEV).train()
+    codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="fp32")
+    B, Tn = 2, 12
+    q = 0.5 * torch.randn(B, 128, Tn, device=DEV)
+    zc, zs, nz = torch.randn(B, 128, device=DEV), torch.randn(B, 128, device=DEV), torch.randn(B, 32, device=DEV)
+    nz2 = torch.randn(B, 32, device=DEV)
+    qr, qg = 0.5 * torch.randn(B, 128, Tn, device=DEV), 0.5 * torch.randn(B, 128, Tn, device=DEV)
+    cfg = T.CodecStageTrainConfig(stage_name="stage3", epochs=1, d_step_period=1, r1_gamma=2.0, r1_interval=1,
+                                  weights=CodecTrainWeights(content=0.0, style=0.0, mode_seeking=0.7))
+    results = []
+    for sink in (True, False):
+        G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="fp32").to(DEV).train()
+        D = MultiScaleWaveDiscriminator(2, precision="fp32").to(DEV).train()
+        G.load_state_dict(G0.state_dict())
+        D.load_state_dict(D0.state_dict())
+        og, od = FusedAdamW(G.parameters(), lr=1e-3, betas=cfg.betas), FusedAdamW(D.parameters(), lr=1e-3, betas=cfg.betas)
+        ops.WGRAD_SINK = sink
+        try:
+            out = T.codec_train_iteration(cfg, G, D, codec, og, od, q, zc, zs, nz, qr, qg, global_step=1, noise2=nz2)
+        finally:
+            ops.WGRAD_SINK = True
+        results.append((og.flat_p.clone(), od.flat_p.clone(), float(out["loss_g"]), float(out["loss_d"]), float(out["loss_ms"]),
+                        og.flat_g.clone(), od.flat_g.clone()))
+    a, b = results
+    assert a[2] == pytest.approx(b[2], rel=1e-6) and a[3] == pytest.approx(b[3], rel=1e-6) and a[4] == pytest.approx(b[4], rel=1e-6)
+    # the gradient buffers (what the two paths differ in) agree to fp32 summation order ...
+    for ga, gb, name in ((a[5], b[5], "G grad"), (a[6], b[6], "D grad")):
+        assert float(gb.abs().max()) > 0
+        err = float((ga - gb).abs().max() / gb.abs().max())
+        assert err <= 2e-6, (name, err)
+    # ... and so do the parameters after the step, up to what AdamW's first step (lr * g / (|g| + eps)) makes of that noise
+    for pa, pb, name in ((a[0], b[0], "G"), (a[1], b[1], "D")):
+        err = float((pa - pb).abs().max() / pb.abs().max())
+        assert err <= 1e-4, (name, err)
