@@ -84,6 +84,7 @@ _SIGNATURES = {
     "ga_conv_kernel_id": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_suggest_ksplit": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
+    "ga_conv_splitk_static": [C.POINTER(ConvParams), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
     "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
@@ -147,7 +148,9 @@ def lib():
 
 
 _ERR = {1: "GA_ERR_ARG (bad shape / unsupported configuration)", 2: "GA_ERR_LAUNCH (HIP launch failed)",
-        3: "GA_ERR_ALIGN (pointer alignment)"}
+        3: "GA_ERR_ALIGN (pointer alignment)", 4: "GA_ERR_UNSUPPORTED (this variant does not take the shape)",
+        5: "GA_ERR_SCRATCH (problem larger than the library's fixed split-K scratch: use ga_conv with a workspace)"}
+SPLITK_STATIC_FLOATS = 8 << 20
 
 
 def check(rc: int, what: str) -> None:

@@ -9,6 +9,7 @@ int ga_conv_gemm_supported(const ConvParams& p);
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_finish(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_suggest_ksplit(const ConvParams& p);
+int ga_conv_splitk_static_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_stream_supported(const ConvParams& p);
 int ga_conv_stream_impl(const ConvParams& p, hipStream_t s);
 int ga_wgrad_mfma_supported(const WgradParams& p);
@@ -66,6 +67,11 @@ int ga_conv_suggest_ksplit(const ga_conv_params* hp, int dtype, int impl) {
 int ga_conv_finish(const ga_conv_params* hp, int dtype, hipStream_t s) {
     if (!hp || dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
     return ga_conv_gemm_finish(*hp, s);
+}
+
+int ga_conv_splitk_static(const ga_conv_params* hp, int dtype, hipStream_t s) {
+    if (!hp || dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
+    return ga_conv_splitk_static_impl(*hp, s);
 }
 
 int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {

@@ -619,3 +619,58 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!nbuf) nbuf = blocks >= gemm_single_min_blocks() ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Split-K through a library-owned scratch: the one entry point that allocates nothing (include/gan_amd.h,
+// ga_conv_splitk_static).  The partial-sum slabs of conv_gemm_kernel + conv_finish_kernel live in a file-scope device
+// array instead of a caller workspace.  Each GPU the library runs on holds its own copy of the array (32 MiB) at its own
+// address until the process ends; the array's NAME is only a host-side handle, so the device address is looked up once per
+// device with hipGetSymbolAddress and that pointer, never the name, is what the kernels receive.
+#include <atomic>
+#include <mutex>
+
+#define GA_SPLITK_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) float ga_splitk_scratch[GA_SPLITK_STATIC_FLOATS];
+static std::atomic<float*> splitk_scratch_ptr[GA_SPLITK_STATIC_MAX_DEVICES];
+static std::mutex splitk_scratch_mutex;
+
+// the calling thread's current device's copy of the scratch array (nullptr: lookup failed)
+static float* splitk_scratch_for_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GA_SPLITK_STATIC_MAX_DEVICES) return nullptr;
+    float* ptr = splitk_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (ptr) return ptr;
+    std::lock_guard<std::mutex> lock(splitk_scratch_mutex);
+    ptr = splitk_scratch_ptr[dev].load(std::memory_order_relaxed);
+    if (ptr) return ptr;
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(ga_splitk_scratch)) != hipSuccess || !sym) return nullptr;
+    ptr = (float*)sym;
+    splitk_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    return ptr;
+}
+
+int ga_conv_splitk_static_impl(const ConvParams& p0, hipStream_t s) {
+    if (!ga_conv_gemm_supported(p0) || !p0.x || !p0.w || !p0.y) return GA_ERR_ARG;
+    if (p0.ws) return GA_ERR_ARG;  // the library supplies the workspace here; a caller-owned one goes through ga_conv
+    if (p0.Lout == 0) return GA_OK;
+    ConvParams p = p0;
+    const int nsteps = (p.J * p.Cin + GBK - 1) / GBK;
+    if (p.ksplit <= 1) {  // library's choice, at least two slices (this entry point IS the split-K path)
+        p.ksplit = ga_conv_gemm_suggest_ksplit(p);
+        if (p.ksplit < 2) p.ksplit = 2;
+    }
+    if (p.ksplit > nsteps) p.ksplit = nsteps;
+    if (p.ksplit < 2) return GA_ERR_UNSUPPORTED;  // a single 64-deep K step cannot be split
+    const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
+    const size_t need = (size_t)p.ksplit * (size_t)p.B * item_elems;
+    if (need > (size_t)GA_SPLITK_STATIC_FLOATS) return GA_ERR_SCRATCH;
+    float* const scratch = splitk_scratch_for_current_device();
+    if (!scratch) return GA_ERR_LAUNCH;
+    p.ws = scratch;
+    // Nothing needs clearing: every slab word conv_finish_kernel reads was written by this call's conv_gemm_kernel (both
+    // walk the same rows / channels of the problem), so what an earlier call left in the array is never observed.
+    const int rc = ga_conv_gemm_impl(p, s);
+    if (rc != GA_OK) return rc;
+    return ga_conv_gemm_finish(p, s);
+}

@@ -31,6 +31,7 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 #define GA_ERR_LAUNCH 2
 #define GA_ERR_ALIGN 3
 #define GA_ERR_UNSUPPORTED 4 /* the fused / fast variant asked for does not take this shape: use the general entry points */
+#define GA_ERR_SCRATCH 5     /* ga_conv_splitk_static: the problem needs more than the library's fixed scratch array */
 
 #define GA_DTYPE_F32 0
 #define GA_DTYPE_BF16 1
@@ -114,6 +115,22 @@ int ga_conv(const ga_conv_params* h_params, int dtype, int impl, ga_stream_t str
  * ga_conv_finish: y = epi(ws) over the rows the problem covers, after a ga_conv launch with ksplit > 1. */
 int ga_conv_suggest_ksplit(const ga_conv_params* h_params, int dtype, int impl);
 int ga_conv_finish(const ga_conv_params* h_params, int dtype, ga_stream_t stream);
+
+/* Split-K convolution that allocates nothing: ga_conv with ksplit > 1 followed by ga_conv_finish, with the partial-sum
+ * slabs in a scratch array that is part of the library's code object instead of a caller workspace.
+ * No counterpart in the reference.  It is for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It calls no hipMalloc / hipFree / allocating library routine.
+ *   - h_params as for ga_conv (bf16 problems the gathered-GEMM kernel takes; inputs and outputs are still the caller's);
+ *     ws must be NULL; ksplit <= 1 lets the library choose (at least 2), otherwise it is used (capped at the K steps).
+ *   - limit: ksplit * B * LoutTot * M (y_batch_elems per item when set) <= GA_SPLITK_STATIC_FLOATS fp32 words (32 MiB);
+ *     larger problems return GA_ERR_SCRATCH and launch nothing: use ga_conv + ga_conv_finish with a workspace.
+ *   - every GPU the library runs on holds its own copy of the array until the process ends.  All calls on one GPU share
+ *     it: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered and safe.  The
+ *     array keeps the previous call's contents; nothing has to be cleared because every word the finishing kernel reads
+ *     is written first by the same call.
+ *   - the first call on a device looks the array's address up (hipGetSymbolAddress); make that call outside graph capture. */
+#define GA_SPLITK_STATIC_FLOATS (8u << 20)
+int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t stream);
 
 /* which kernel ga_conv would launch for these parameters (for tests and the benchmark's per-kernel accounting) */
 #define GA_KERNEL_DIRECT_TILE 0
