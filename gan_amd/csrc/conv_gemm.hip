@@ -593,9 +593,13 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     return GA_OK;
 }
 
+int ga_conv_pp_wanted(const ConvParams& p);
+int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
+
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
+    if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
     // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
     // wants the second buffer
     const int ksteps = (p.J * p.Cin + GBK - 1) / GBK;

@@ -254,8 +254,9 @@ __device__ __forceinline__ void seg_mma2(const WT* a0, const WT* const (&b0)[NBT
 }
 
 template <typename WT, typename AT, int H, int NBT, int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_fast_kernel(ga_lstm_params p, int s, int b_base) {
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_fast_kernel(ga_lstm_params p, int s, int b_base0) {
     __shared__ float red[NW][NBT][16][17];
+    const int b_base = b_base0 + blockIdx.z * (NBT * 16);  // batch chunks of one step run side by side (grid z), not as a chain of launches
     constexpr int KS = Mma<WT>::KSTEP;
     const int layer = blockIdx.y;
     const int t = layer == 0 ? s : s - 1;
@@ -350,8 +351,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_fast_kernel(ga_lstm_params p
 }
 
 template <typename WT, typename AT, int H, int NBT, int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p, int s, int b_base) {
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_fast_kernel(ga_lstm_bwd_params p, int s, int b_base0) {
     __shared__ float red[NW][NBT][16][17];
+    const int b_base = b_base0 + blockIdx.z * (NBT * 16);
     constexpr int KS = Mma<WT>::KSTEP;
     constexpr int NK = 4 * H / KS / NW;
     const int layer = blockIdx.y;  // 0: layer 2 (leads), 1: layer 1
@@ -459,6 +461,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_fast_kernel(ga_lstm_bwd_para
 template <typename WT, typename AT, int H>
 static void launch_fwd_fast(const ga_lstm_params& p, int st, hipStream_t s) {
     constexpr int FNW = GA_LSTM_FNW;
+    if (p.B > 64) {  // every 64-item chunk of the step in ONE launch (columns past B are clamped on load and never stored)
+        const dim3 gridz(H / 4, 2, (p.B + 63) / 64);
+        lstm_fwd_fast_kernel<WT, AT, H, 4, FNW><<<gridz, FNW * 64, 0, s>>>(p, st, 0);
+        return;
+    }
     const dim3 grid(H / 4, 2);
     for (int b0 = 0; b0 < p.B; b0 += 64) {
         const int nbt = (((p.B - b0) < 64 ? (p.B - b0) : 64) + 15) / 16;
@@ -474,6 +481,11 @@ static void launch_fwd_fast(const ga_lstm_params& p, int st, hipStream_t s) {
 template <typename WT, typename AT, int H>
 static void launch_bwd_fast(const ga_lstm_bwd_params& p, int st, hipStream_t s) {
     constexpr int BNW = GA_LSTM_BNW;
+    if (p.B > 32) {
+        const dim3 gridz(H / 16, 2, (p.B + 31) / 32);
+        lstm_bwd_fast_kernel<WT, AT, H, 2, BNW><<<gridz, BNW * 64, 0, s>>>(p, st, 0);
+        return;
+    }
     const dim3 grid(H / 16, 2);
     for (int b0 = 0; b0 < p.B; b0 += 32) {
         const int nbt = (((p.B - b0) < 32 ? (p.B - b0) : 32) + 15) / 16;

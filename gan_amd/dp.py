@@ -174,6 +174,21 @@ class DataParallel:
         g = _AllReduceSums.apply(sums, self.group)
         return g, count * self.world_size
 
+    def broadcast_state(self, start_epoch: int, *opts) -> int:
+        """Rank 0's parameters, AdamW moments, step counters and resume epoch to every rank (train_codec_stage calls this once
+        after the optimizers are built / a checkpoint is loaded).  Returns rank 0's start epoch."""
+        self.broadcast_params(*opts)
+        meta = torch.tensor([float(start_epoch)] + [float(o.step_count) for o in opts], dtype=torch.float64,
+                            device=opts[0].flat_p.device)
+        dist.broadcast(meta, src=0, group=self.group)
+        for opt in opts:
+            dist.broadcast(opt.exp_avg, src=0, group=self.group)
+            dist.broadcast(opt.exp_avg_sq, src=0, group=self.group)
+        vals = meta.tolist()
+        for o, v in zip(opts, vals[1:]):
+            o.step_count = int(v)
+        return int(vals[0])
+
     def broadcast_params(self, *opts) -> None:
         for opt in opts:
             dist.broadcast(opt.flat_p, src=0, group=self.group)

@@ -1,0 +1,102 @@
+"""Waveform -> Lab1 log-mel adapter of the G step's content / Lab1-style terms (reference `_Lab1WaveAdapter`,
+lab 3/src/lab3_codec_train.py:179-222), restated without torchaudio.
+
+The reference builds this from three torchaudio pieces, none of which is importable in this image, so what is restated
+here is their PUBLISHED algorithm (torchaudio 2.x `functional.resample`, `transforms.MelSpectrogram`,
+`transforms.AmplitudeToDB`); no fixture of the reference can pin it here: **parity unpinned** (DESIGN.md section 8b).
+
+  resample 24 kHz -> 22.05 kHz: windowed-sinc polyphase filter, `sinc_interp_hann`, lowpass_filter_width 64, rolloff
+      0.9475937167399596 (:200-207): gcd 150 -> 160 input samples per 147 output samples, 308-tap kernels, zero padding
+      (width, width + 160), one strided conv, output trimmed to ceil(147 * S / 160).
+  MelSpectrogram(sr, n_fft 1024, hop 256, 96 mels, f_min 20, f_max sr/2, power 2, center, reflect pad, periodic Hann,
+      HTK mel scale, norm None) (:185-194), clamp_min(1e-8) (:208).
+  AmplitudeToDB(stype "power", top_db 80) (:195): 10*log10(max(x, 1e-10)), then clamped from below at (max over the WHOLE
+      [B, 96, T] tensor) - 80: torchaudio treats a 3-D input as one multi-channel spectrogram, so the floor is shared by the
+      batch.
+  crop (centre) or pad (-80) to n_frames (:210-221).
+
+Everything runs on the device the waveform lives on; autograd carries the gradient back to x_hat.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 64,
+                         rolloff: float = 0.9475937167399596, dtype=torch.float32, device="cpu") -> Tuple[torch.Tensor, int, int, int]:
+    """[new, 1, 2*width + orig] polyphase kernels of torchaudio's `_get_sinc_resample_kernel` (sinc_interp_hann), computed in
+    `dtype` as torchaudio does for a waveform of that dtype.  Returns (kernel, width, orig/gcd, new/gcd)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * float(rolloff)
+    width = int(math.ceil(lowpass_filter_width * orig / base_freq))
+    idx = torch.arange(-width, width + orig, dtype=dtype, device=device)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=dtype, device=device)[:, None, None] / new + idx
+    t = t * base_freq
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
+    kernels = kernels * window * scale
+    return kernels, width, orig, new
+
+
+def resample(wave: torch.Tensor, kernel: torch.Tensor, width: int, orig: int, new: int) -> torch.Tensor:
+    """torchaudio `_apply_sinc_resample_kernel` on [B, S] -> [B, ceil(new*S/orig)]."""
+    B, S = wave.shape
+    x = F.pad(wave, (width, width + orig))
+    y = F.conv1d(x[:, None], kernel, stride=orig)           # [B, new, frames]
+    y = y.transpose(1, 2).reshape(B, -1)
+    return y[:, : int(math.ceil(new * S / orig))]
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int, device="cpu") -> torch.Tensor:
+    """[n_freqs, n_mels] triangular filters, HTK mel scale, norm None (torchaudio.functional.melscale_fbanks)."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, device=device)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2, device=device)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)
+
+
+class Lab1WaveAdapter:
+    """Same constructor and call as the reference's `_Lab1WaveAdapter` (:179-222): wav [B, 1, S] -> log-mel dB [B, 96, n_frames]."""
+
+    def __init__(self, codec_sr: int, lab1_sr: int, n_frames: int, device: torch.device):
+        self.codec_sr, self.lab1_sr, self.n_frames, self.device = int(codec_sr), int(lab1_sr), int(n_frames), device
+        self.n_fft, self.hop, self.n_mels = 1024, 256, 96
+        if self.codec_sr != self.lab1_sr:
+            k, self.width, self.orig, self.new = sinc_resample_kernel(self.codec_sr, self.lab1_sr, device=device)
+            self.kernel = k
+        else:
+            self.kernel = None
+        self.window = torch.hann_window(self.n_fft, periodic=True, device=device)
+        self.fb = melscale_fbanks(self.n_fft // 2 + 1, 20.0, float(self.lab1_sr) * 0.5, self.n_mels, self.lab1_sr, device=device)
+
+    def __call__(self, wav_b_1_t: torch.Tensor) -> torch.Tensor:
+        y = wav_b_1_t.squeeze(1).float()
+        if self.kernel is not None:
+            y = resample(y, self.kernel, self.width, self.orig, self.new)
+        spec = torch.stft(y, self.n_fft, hop_length=self.hop, win_length=self.n_fft, window=self.window, center=True,
+                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        power = spec.real ** 2 + spec.imag ** 2                            # [B, 513, frames]
+        mel = torch.matmul(power.transpose(-1, -2), self.fb).transpose(-1, -2).clamp_min(1e-8)
+        mel_db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+        mel_db = torch.max(mel_db, (mel_db.detach().amax() - 80.0))       # top_db over the whole batch tensor (see module doc)
+        t = int(mel_db.shape[-1])
+        if t > self.n_frames:
+            start = (t - self.n_frames) // 2
+            mel_db = mel_db[:, :, start:start + self.n_frames]
+        elif t < self.n_frames:
+            mel_db = torch.cat([mel_db, mel_db.new_full((mel_db.shape[0], mel_db.shape[1], self.n_frames - t), -80.0)], dim=2)
+        return mel_db

@@ -204,17 +204,37 @@ class CodecConfig:
 
 class FrozenEncodec:
     """The part of the reference's FrozenEncodec that sits on the training hot path: `.cfg` and
-    `.decode_embeddings(q[B,C,T]) -> wav[B,1,S]`, differentiable w.r.t. q.  Construct it from an HF decoder
-    state dict (or leave the random init for synthetic benchmarks)."""
+    `.decode_embeddings(q[B,C,T]) -> wav[B,1,S]`, differentiable w.r.t. q.
 
-    def __init__(self, decoder_state_dict: Optional[dict] = None, device: str = "cuda", precision: str = "fp32",
-                 chunk_seconds: float = 5.0):
+    Same constructor arguments as the reference (lab3_codec_bridge.py:33-60: model_id, bandwidth, chunk_seconds, device), so
+    `FrozenEncodec(model_id=..., bandwidth=..., chunk_seconds=..., device=...)` keeps working: like the reference it then
+    fetches the pretrained model through `transformers.EncodecModel.from_pretrained(model_id)` and copies the decoder's
+    state dict into the native decoder.  Extra keywords: `decoder_state_dict` (an HF decoder state dict the caller already
+    holds: no transformers call), `random_init=True` (keep the random initialisation: synthetic benchmarks and tests, no
+    network), `precision` ("fp32" | "bf16")."""
+
+    def __init__(self, model_id: str = "facebook/encodec_24khz", bandwidth: float = 6.0, chunk_seconds: float = 5.0,
+                 device: str = "auto", *, decoder_state_dict: Optional[dict] = None, random_init: bool = False,
+                 precision: str = "fp32"):
+        if device == "auto":  # reference _to_device (:27-30)
+            device = "cuda" if torch.cuda.is_available() else "cpu"
         self.device = device
+        self.model_id = str(model_id)
         self.decoder = SeanetDecoder(precision=precision)
+        cfg = CodecConfig(model_id=self.model_id, chunk_seconds=float(chunk_seconds), bandwidth=float(bandwidth))
+        if decoder_state_dict is None and not random_init:
+            from transformers import EncodecModel  # the reference's own loading step (:43): a fetch by model name
+            hf = EncodecModel.from_pretrained(self.model_id)
+            decoder_state_dict = hf.decoder.state_dict()
+            hc = hf.config
+            cfg = CodecConfig(model_id=self.model_id, sample_rate=int(getattr(hc, "sampling_rate", 24000)),
+                              chunk_seconds=float(chunk_seconds), bandwidth=float(bandwidth), codebook_size=int(hc.codebook_size),
+                              num_codebooks=int(hc.num_quantizers), latent_channels=int(getattr(hc, "hidden_size", 128)),
+                              frame_rate=float(getattr(hf.quantizer, "frame_rate", None) or 75.0))
         if decoder_state_dict is not None:
             self.decoder.load_state_dict(decoder_state_dict, strict=True)
         self.decoder.to(device)
-        self.cfg = CodecConfig(chunk_seconds=float(chunk_seconds))
+        self.cfg = cfg
 
     def decode_embeddings(self, q_emb_b_c_t: torch.Tensor) -> torch.Tensor:
         return self.decoder(q_emb_b_c_t.to(self.device))

@@ -7,8 +7,10 @@ Mirrors (same names / signatures / return structures):
   train_codec_stage (:267-648).
 The loop body lives in `codec_train_iteration`, which takes the per-iteration random picks as explicit tensors so
 that parity tests can inject them.  Loss terms covered: adv, feature matching, latent L1, continuity, MR-STFT,
-delta budget, mode seeking.  The Lab1 content term and the judge/probe style terms need modules outside this
-path and raise NotImplementedError when requested.
+delta budget, mode seeking, and - when the caller passes the reference's frozen modules - the Lab1 content term and every
+style mode (`lab1_cos`, `codec_judge_ce`, `lab1_probe_ce`, `mert_probe_ce`, :472-550): x_hat goes through
+gan_amd.lab1_adapter.Lab1WaveAdapter (the torchaudio-free restatement of `_Lab1WaveAdapter`, :179-222) and the caller's
+`lab1_encoder.forward_log_mel_tensor`, which runs as the ordinary PyTorch module it is.
 """
 from __future__ import annotations
 
@@ -176,10 +178,28 @@ def _save_stage_checkpoint(ckpt_path: Path, epoch: int, generator, discriminator
     torch.save(payload, str(ckpt_path))
 
 
+def _plain_config(stage_cfg) -> Dict:
+    """meta.config as plain data (the reference stores stage_cfg.__dict__, :645, which pickles a dataclass instance; plain
+    dicts / lists / numbers load with torch.load(weights_only=True) and need neither package importable)."""
+    import dataclasses
+    d = dataclasses.asdict(stage_cfg)
+    d["betas"] = [float(b) for b in d["betas"]]
+    d["wave_mrstft_resolutions"] = [[int(v) for v in r] for r in d["wave_mrstft_resolutions"]]
+    return d
+
+
 def _try_load_stage_checkpoint(ckpt_path: Path, generator, discriminator, opt_g, opt_d, device) -> int:
     if not ckpt_path.exists():
         return 0
-    payload = torch.load(str(ckpt_path), map_location=device, weights_only=False)  # file written by this code
+    try:
+        payload = torch.load(str(ckpt_path), map_location=device, weights_only=True)
+    except Exception as e:  # a checkpoint whose meta pickles objects (the reference writes its dataclasses into meta.config)
+        import os
+        if os.environ.get("GAN_AMD_TRUST_CHECKPOINT", "0") != "1":
+            raise RuntimeError(f"{ckpt_path} holds pickled objects beyond tensors and plain data ({type(e).__name__}); it was not "
+                               "written by gan_amd.  Set GAN_AMD_TRUST_CHECKPOINT=1 to unpickle it (this executes code from the "
+                               "file and needs the writer's modules importable).") from e
+        payload = torch.load(str(ckpt_path), map_location=device, weights_only=False)
     generator.load_state_dict(payload["generator"], strict=True)
     discriminator.load_state_dict(payload["discriminator"], strict=True)
     opt_g.load_state_dict(payload["opt_g"])
@@ -231,10 +251,13 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
                           noise2: Optional[torch.Tensor] = None, dp=None, prefetcher=None,
                           next_frozen: Optional[List[torch.Tensor]] = None, style_judge=None,
                           tgt_genre_idx: Optional[torch.Tensor] = None,
-                          src_genre_idx: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                          src_genre_idx: Optional[torch.Tensor] = None, lab1_encoder=None, lab1_adapter=None,
+                          lab1_probe=None, mert_probe=None, zs_src: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """One iteration of the reference loop body (:404-591).  Returns device scalars (no host sync).
     style_judge (+ tgt_genre_idx / src_genre_idx, device int64 [B]): the frozen CodecStyleJudge of style_loss_mode
-    "codec_judge_ce" (:480-494); None leaves the style terms at zero.
+    "codec_judge_ce" (:480-494).  lab1_encoder + lab1_adapter (+ zs_src, lab1_probe, mert_probe): the content term and the
+    Lab1 / probe style modes (:472-475,495-550), the caller's frozen modules run as ordinary PyTorch on the log-mel of x_hat.
+    With neither a judge nor a Lab1 encoder the content and style terms stay at zero (the north-star loss subset).
     prefetcher / next_frozen: see gan_amd/prefetch.py - the frozen latents of the NEXT iteration ([q_src, q_real_tgt (if
     that iteration takes a D step), q_real_tgt_g]) are decoded on a side stream while this iteration runs."""
     device = q_src.device
@@ -325,13 +348,44 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     loss_style_push = zero
     loss_ms = zero
     w = stage_cfg.weights
-    if style_judge is not None and str(stage_cfg.style_loss_mode).strip().lower() == "codec_judge_ce":
-        from .lab3_codec_judge import codec_judge_style_terms
+    style_mode = str(stage_cfg.style_loss_mode).strip().lower()
+    stage1 = str(stage_cfg.stage_name) == "stage1"
+    out_hat = None
+    if lab1_encoder is not None:
+        # content term (:472-475): x_hat -> resample / mel / dB (gan_amd.lab1_adapter) -> the caller's frozen Lab1 encoder
+        mel_hat = lab1_adapter(x_hat)
+        out_hat = lab1_encoder.forward_log_mel_tensor(mel_hat)
+        zc_hat = F.normalize(out_hat["z_content"], dim=-1)
+        loss_content = (1.0 - F.cosine_similarity(zc_hat, zc_src, dim=-1)).mean()
+    from .lab3_codec_judge import codec_judge_style_terms
+
+    def judge_terms(mod, inp):
         if tgt_genre_idx is None or src_genre_idx is None:
-            raise ValueError("style_judge needs tgt_genre_idx and src_genre_idx")
-        loss_style, loss_style_embed, loss_style_push = codec_judge_style_terms(
-            style_judge, q_hat, z_style_tgt, tgt_genre_idx, src_genre_idx, float(stage_cfg.style_embed_align_weight),
-            float(stage_cfg.style_push_margin), stage1=str(stage_cfg.stage_name) == "stage1")
+            raise ValueError("the style judge / probe terms need tgt_genre_idx and src_genre_idx")
+        return codec_judge_style_terms(mod, inp, z_style_tgt, tgt_genre_idx, src_genre_idx,
+                                       float(stage_cfg.style_embed_align_weight), float(stage_cfg.style_push_margin), stage1=stage1)
+
+    def lab1_cos_terms(with_push: bool):
+        zs_hat = F.normalize(out_hat["z_style"], dim=-1)
+        ls = (1.0 - F.cosine_similarity(zs_hat, z_style_tgt, dim=-1)).mean()
+        lp = zero
+        if with_push and not stage1:
+            if zs_src is None:
+                raise ValueError("style_loss_mode 'lab1_cos' needs zs_src outside stage1")
+            lp = F.relu(F.cosine_similarity(zs_hat, zs_src, dim=-1) - float(stage_cfg.style_push_margin)).mean()
+        return ls, lp
+
+    if style_mode == "codec_judge_ce" and style_judge is not None:                      # :480-494
+        loss_style, loss_style_embed, loss_style_push = judge_terms(style_judge, q_hat)
+    elif style_mode == "lab1_probe_ce" and lab1_probe is not None and out_hat is not None:  # :495-511
+        loss_style, loss_style_embed, loss_style_push = judge_terms(lab1_probe, F.normalize(out_hat["z_style"], dim=-1))
+    elif style_mode == "mert_probe_ce" and mert_probe is not None:                      # :512-544
+        if style_judge is not None:
+            loss_style, loss_style_embed, loss_style_push = judge_terms(style_judge, q_hat)
+        elif out_hat is not None:
+            loss_style, _ = lab1_cos_terms(with_push=False)
+    elif out_hat is not None:                                                           # :545-550 (lab1_cos and everything else)
+        loss_style, loss_style_push = lab1_cos_terms(with_push=True)
     if float(w.mode_seeking) > 0.0:
         if noise2 is None:
             noise2 = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
@@ -347,9 +401,15 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     if float(w.mode_seeking) > 0.0:
         terms.append(loss_ms)
         wts.append(w.mode_seeking)
-    if style_judge is not None:
-        terms += [loss_style, loss_style_push]
-        wts += [w.style, w.style_push]
+    if loss_content is not zero:
+        terms.append(loss_content)
+        wts.append(w.content)
+    if loss_style is not zero:
+        terms.append(loss_style)
+        wts.append(w.style)
+    if loss_style_push is not zero:
+        terms.append(loss_style_push)
+        wts.append(w.style_push)
     loss_g = ops.weighted_sum(terms, wts)
     opt_g.zero_grad(set_to_none=True)
     opt_g.max_grad_norm = float(stage_cfg.g_grad_clip_norm)
@@ -358,7 +418,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
 
     out.update(loss_g=loss_g.detach(), loss_adv=loss_adv.detach(), loss_fm=loss_fm.detach(),
                loss_lat_l1=loss_lat_l1.detach(), loss_lat_cont=loss_lat_cont.detach(), loss_mrstft=loss_mrstft.detach(),
-               loss_delta_budget=loss_delta_budget.detach(), loss_ms=loss_ms.detach(), loss_content=loss_content,
+               loss_delta_budget=loss_delta_budget.detach(), loss_ms=loss_ms.detach(), loss_content=loss_content.detach(),
                loss_style=loss_style.detach(), loss_style_embed=loss_style_embed.detach(),
                loss_style_push=loss_style_push.detach(), g_grad_norm=opt_g.last_grad_norm,
                q_hat=q_hat.detach(), x_hat=x_hat.detach())
@@ -374,22 +434,25 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
     """reference :267-648.  Same arguments and the same 19-key history rows.  Losses are accumulated on the device and
     read back once per epoch (the reference syncs 12 scalars per iteration, :593-604)."""
     w = stage_cfg.weights
-    if lab1_encoder is not None or lab1_probe is not None or mert_probe is not None:
-        raise NotImplementedError("content / probe terms (Lab1 encoder, Lab1 / MERT probes) are outside the accelerated "
-                                  "path; pass None (SURVEY.md section 8(f) next-1)")
     style_mode = str(stage_cfg.style_loss_mode).strip().lower()
-    use_judge = style_judge is not None and style_mode == "codec_judge_ce"
-    if style_judge is not None:
-        from .lab3_codec_judge import CodecStyleJudge
-        if not isinstance(style_judge, CodecStyleJudge):
-            raise TypeError("style_judge must be a gan_amd.lab3_codec_judge.CodecStyleJudge (load the reference judge's "
-                            "state_dict into one: the keys are the same)")
-        style_judge.eval()  # frozen, as reference :289-292
-        for p in style_judge.parameters():
-            p.requires_grad = False
-    if float(w.content) > 0.0 or ((float(w.style) > 0.0 or float(w.style_push) > 0.0) and not use_judge):
-        warnings.warn("content weight (and style weights without a codec_judge_ce style judge) are ignored: those terms "
-                      "are not part of this path", stacklevel=2)
+    use_judge = style_judge is not None and style_mode in ("codec_judge_ce", "mert_probe_ce")
+    for frozen in (style_judge, lab1_probe, mert_probe):  # frozen, as reference :289-300 (any nn.Module with .embed / .head:
+        if frozen is not None:                            # gan_amd's CodecStyleJudge or the reference's own classes)
+            frozen.eval()
+            for p in frozen.parameters():
+                p.requires_grad = False
+    lab1_adapter = None
+    if lab1_encoder is not None:
+        from .lab1_adapter import Lab1WaveAdapter
+        lab1_adapter = Lab1WaveAdapter(codec_sr=int(codec.cfg.sample_rate), lab1_sr=int(lab1_encoder.cfg.sample_rate),
+                                       n_frames=256, device=device)  # reference :325-330
+    else:
+        # The reference cannot run without a Lab1 encoder (:325-330 dereferences it).  Here None selects the loss subset that
+        # needs none; terms that would silently vanish with a nonzero weight are an error, not a warning.
+        style_needs_lab1 = not (style_mode in ("codec_judge_ce", "mert_probe_ce") and style_judge is not None)
+        if float(w.content) > 0.0 or (style_needs_lab1 and (float(w.style) > 0.0 or float(w.style_push) > 0.0)):
+            raise ValueError("lab1_encoder is None but the content weight (or a style weight whose mode needs the Lab1 encoder) "
+                             "is nonzero: pass the FrozenLab1Encoder as the reference caller does, or set those weights to 0")
     generator.train()
     discriminator.train()
     style_centroid_bank = style_centroid_bank.to(device)
@@ -400,6 +463,10 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
     start_epoch = 0
     if resume:
         start_epoch = _try_load_stage_checkpoint(ckpt_path, generator, discriminator, opt_g, opt_d, device)
+    if dp is not None:
+        # replicas must start from rank 0's parameters AND optimizer state (only rank 0 writes checkpoints, so a resume on
+        # non-shared storage would otherwise diverge silently)
+        start_epoch = dp.broadcast_state(start_epoch, opt_g, opt_d)
 
     hist_rows: List[Dict] = []
     global_step = 0
@@ -416,33 +483,52 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
         acc = {k: torch.zeros((), device=device) for k in keys}
         d_steps_taken = d_steps_skipped = n_batches = 0
         def prepare(bi, batch, step):
-            """Everything one iteration draws or moves (the reference's :361-421,455-457), so that it can be done one batch
-            ahead: the next batch's frozen latents go to the side-stream decode while the current iteration runs."""
+            """Everything one iteration draws or moves before its generator pass (the reference's :361-404,420,456), in the
+            reference's order of random draws.  Without `prefetch` it runs at the top of its own iteration, so a seed gives
+            the reference's sequence of CPU and device draws; with `prefetch` it runs one batch ahead (the next batch's
+            frozen latents go to the side-stream decode) and the draws of batch i+1 precede batch i's in-forward ones."""
             q_src = batch["q_emb"].to(device, non_blocking=True).float()
             zc_src = F.normalize(batch["z_content"].to(device, non_blocking=True).float(), dim=-1)
             zs_src = F.normalize(batch["z_style"].to(device, non_blocking=True).float(), dim=-1)
-            # labels stay on the host: target / exemplar sampling reads them row by row (reference :109-118), and a
-            # device tensor there would cost a stream-draining .cpu() per draw
-            src_genre_idx = batch["genre_idx"].detach().to("cpu").long()
-            if str(stage_cfg.stage_name) == "stage1":
-                tgt_genre_idx = src_genre_idx
-            elif bool(stage_cfg.target_balance):
-                tgt_genre_idx = _sample_shift_targets_balanced(src_genre_idx, n_genres=int(n_genres), offset=epoch + bi)
+            stage1 = str(stage_cfg.stage_name) == "stage1"
+            if stage1 or bool(stage_cfg.target_balance):
+                # labels stay on the host: target / exemplar sampling reads them row by row (reference :109-118), and a
+                # device tensor there would cost a stream-draining .cpu() per draw
+                src_genre_idx = batch["genre_idx"].detach().to("cpu").long()
+                tgt_genre_idx = src_genre_idx if stage1 else _sample_shift_targets_balanced(
+                    src_genre_idx, n_genres=int(n_genres), offset=epoch + bi)
             else:
-                tgt_genre_idx = _sample_shift_targets(src_genre_idx, n_genres=int(n_genres))
+                # the reference draws the shifted targets with the DEVICE generator (labels live on the device, :368,378)
+                src_dev_ = batch["genre_idx"].to(device, non_blocking=True).long()
+                tgt_genre_idx = _sample_shift_targets(src_dev_, n_genres=int(n_genres)).cpu()
+                src_genre_idx = src_dev_.cpu()
             z_style_tgt = _mix_style_condition(tgt_genre_idx, str(stage_cfg.cond_mode), float(alpha), style_centroid_bank,
                                                style_exemplar_bank, device, float(stage_cfg.exemplar_noise_std))
-            if (str(stage_cfg.stage_name) == "stage1" and str(stage_cfg.style_loss_mode).strip().lower() == "lab1_cos"
-                    and int(z_style_tgt.shape[1]) == int(zs_src.shape[1])):
-                z_style_tgt = zs_src
+            if stage1:  # reference :389-402
+                if style_mode == "lab1_cos" and int(z_style_tgt.shape[1]) == int(zs_src.shape[1]):
+                    z_style_tgt = zs_src
+                elif style_mode == "lab1_probe_ce" and lab1_probe is not None:
+                    with torch.no_grad():
+                        z_style_tgt = lab1_probe.embed(zs_src).detach()
+                elif style_mode == "mert_probe_ce" and mert_probe is not None and batch.get("mert_feat") is not None:
+                    with torch.no_grad():
+                        z_style_tgt = mert_probe.embed(batch["mert_feat"].to(device).float()).detach()
             noise = generator.sample_noise(batch_size=int(q_src.shape[0]), device=device)
             take_d = (step % max(1, int(stage_cfg.d_step_period))) == 0
-            q_real_tgt = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float() if take_d else None
-            q_real_tgt_g = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float()
-            tgt_dev = tgt_genre_idx.to(device, non_blocking=True) if use_judge else None
-            src_dev = src_genre_idx.to(device, non_blocking=True) if use_judge else None
-            return dict(q_src=q_src, zc_src=zc_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, q_real_tgt=q_real_tgt,
-                        q_real_tgt_g=q_real_tgt_g, step=step, tgt_genre_idx=tgt_dev, src_genre_idx=src_dev)
+            need_idx = use_judge or lab1_probe is not None
+            tgt_dev = tgt_genre_idx.to(device, non_blocking=True) if need_idx else None
+            src_dev = src_genre_idx.to(device, non_blocking=True) if need_idx else None
+            item = dict(q_src=q_src, zc_src=zc_src, zs_src=zs_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, step=step,
+                        tgt_genre_idx=tgt_dev, src_genre_idx=src_dev, tgt_host=tgt_genre_idx)
+            if prefetcher is not None:
+                draw_bank_rows(item)
+            return item
+
+        def draw_bank_rows(item):
+            """q_real_tgt (D step, :420) then q_real_tgt_g (G step, :456): CPU-generator picks, in the reference's order."""
+            item["q_real_tgt"] = (_sample_bank_rows(q_exemplar_bank, item["tgt_host"], device=device).float()
+                                  if item["take_d"] else None)
+            item["q_real_tgt_g"] = _sample_bank_rows(q_exemplar_bank, item["tgt_host"], device=device).float()
 
         def frozen_of(item):
             return [item["q_src"]] + ([item["q_real_tgt"]] if item["take_d"] else []) + [item["q_real_tgt_g"]]
@@ -460,13 +546,22 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             global_step += 1
             n_batches += 1
             nxt = next(it, None)
-            ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
+            ahead = None
+            if prefetcher is not None:
+                ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
+            else:
+                # No device-side random draw separates these two host picks from their place in the reference (:420, :456), and
+                # the G forward's own draws (dropout, jitter) come after prepare()'s, as there.
+                draw_bank_rows(cur)
             take_d = cur["take_d"]
             res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, cur["q_src"], cur["zc_src"],
                                         cur["z_style_tgt"], cur["noise"], cur["q_real_tgt"], cur["q_real_tgt_g"], global_step,
                                         dp=dp, prefetcher=prefetcher, next_frozen=frozen_of(ahead) if ahead is not None else None,
-                                        style_judge=style_judge if use_judge else None,
-                                        tgt_genre_idx=cur["tgt_genre_idx"], src_genre_idx=cur["src_genre_idx"])
+                                        style_judge=style_judge, tgt_genre_idx=cur["tgt_genre_idx"],
+                                        src_genre_idx=cur["src_genre_idx"], lab1_encoder=lab1_encoder, lab1_adapter=lab1_adapter,
+                                        lab1_probe=lab1_probe, mert_probe=mert_probe, zs_src=cur["zs_src"])
+            if prefetcher is None:
+                ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
             cur = ahead
             if take_d:
                 d_steps_taken += 1
@@ -494,5 +589,5 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
         hist_rows.append(row)
         if dp is None or dp.rank == 0:
             _save_stage_checkpoint(ckpt_path, int(epoch), generator, discriminator, opt_g, opt_d,
-                                   {"stage": str(stage_cfg.stage_name), "config": stage_cfg.__dict__})
+                                   {"stage": str(stage_cfg.stage_name), "config": _plain_config(stage_cfg)})
     return hist_rows

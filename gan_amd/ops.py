@@ -132,10 +132,12 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
-    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA):
+    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_PP):
         p, bias = _fold_phases(p, x, bias)
     # few output tiles x deep K (D blocks 3-4): split K over workgroups, one fp32 partial-sum slab per slice
     ks = L.lib().ga_conv_suggest_ksplit(C.byref(p), L.dt(x), impl) if SPLIT_K else 1
+    if FORCE_KSPLIT is not None and L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl) in (7, 8, 9, 11):
+        ks = max(1, min(int(FORCE_KSPLIT), (p.J * p.Cin + 63) // 64))
     ws = None
     if ks > 1:
         ws = torch.empty((ks * p.B * p.LoutTot * p.M,), device=x.device, dtype=torch.float32)
@@ -200,6 +202,7 @@ def _fold_phases(p: L.ConvParams, x: Tensor, bias):
 MERGE_PHASES = True  # tests switch this off to compare against the phase-by-phase launches
 _IMPL = L.IMPL_AUTO
 WGRAD_SLABS = False  # True: per-slice slabs + a reduce kernel instead of fp32 atomics on dw (measured no faster; tests run both)
+FORCE_KSPLIT = None  # tuning aid (scratch/bench_conv.py): this split for every gathered-GEMM launch
 SPLIT_K = True  # tests switch this off to compare split-K against the single-pass kernel
 PROFILE = None  # set to a list by bench.py to collect (kernel id, launched flops, start event, end event)
 
@@ -285,7 +288,7 @@ def fm_sign_fusable(g: ConvGeom, gy: Tensor, lin: int) -> bool:
     p.x = p.w = p.y = p.res = p.dact_src = p.res_coef_dev = 256  # alignment checks only: nothing is dereferenced
     if MERGE_PHASES:
         p, _ = _fold_phases(p, gy, None)
-    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(gy), _IMPL) in (7, 8, 9)
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(gy), _IMPL) in (7, 8, 9, 11)
 
 
 def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):

@@ -50,6 +50,8 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 #define GA_IMPL_DIRECT 1 /* vector-ALU fp32 FMA chains (exact fp32 mode, thin layers) */
 #define GA_IMPL_MFMA 2   /* bf16 MFMA implicit GEMM (gathered-GEMM kernel when it applies, else the window kernel); error if unsupported */
 #define GA_IMPL_MFMA_WINDOW 3 /* force the LDS-window MFMA kernel (conv_mfma_kernel) */
+#define GA_IMPL_MFMA_PP 4     /* force the ping-pong gathered-GEMM kernel (conv_pp_kernel: 256x256 tiles, eight waves); error if
+                                 unsupported.  AUTO / MFMA pick it by themselves for deep-K layers with >= 192 output channels */
 
 #define GA_MAX_PHASE 8
 
@@ -144,6 +146,7 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_GEMM_128x128 8 /* conv_gemm_kernel<2,2,2>; <1,2,2> (64x128 tiles) for grids of few workgroups */
 #define GA_KERNEL_GEMM_32x256 9  /* conv_gemm_kernel<1,1,4> */
 #define GA_KERNEL_STREAM 10      /* conv_stream_kernel: M <= 64, K <= 192, operands straight from global memory */
+#define GA_KERNEL_GEMM_PP 11     /* conv_pp_kernel: 256x256 tiles, wave tile 128x64, ping-pong schedule (deep K, M >= 192) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]

@@ -2,7 +2,7 @@
 import sys, time, torch
 sys.path.insert(0, ".")
 from gan_amd.lab3_codec_bridge import FrozenEncodec
-codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="bf16")
+codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
 dec = codec.decoder
 qa = 0.5 * torch.randn(12, 128, 375, device="cuda")
 qb = 0.5 * torch.randn(36, 128, 375, device="cuda")

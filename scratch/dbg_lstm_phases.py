@@ -2,7 +2,7 @@ import os, sys, torch, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gan_amd import _lib as L, ops
 from gan_amd.lab3_codec_bridge import FrozenEncodec
-codec = FrozenEncodec(decoder_state_dict=None, device=torch.device("cuda"), precision="bf16")
+codec = FrozenEncodec(random_init=True, device=torch.device("cuda"), precision="bf16")
 lstm = [m for m in codec.decoder.modules() if type(m).__name__.lower().find("lstm") >= 0]
 print([type(m).__name__ for m in lstm])
 q = torch.randn(36, 128, 375, device="cuda")

@@ -15,7 +15,7 @@ def build_gpu_models(g_sd, d_sd, dec_sd, precision: str, device="cuda", **gkw):
     n_scales = len({k.split(".")[1] for k in d_sd})
     D = MultiScaleWaveDiscriminator(n_scales, precision=precision)
     D.load_state_dict(d_sd, strict=True)
-    codec = FrozenEncodec(decoder_state_dict=dec_sd, device=device, precision=precision)
+    codec = FrozenEncodec(decoder_state_dict=dec_sd, random_init=dec_sd is None, device=device, precision=precision)
     return G.to(device).train(), D.to(device).train(), codec
 
 

@@ -808,7 +808,7 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("B,T", [(3, 20), (18, 7)])
+@pytest.mark.parametrize("B,T", [(3, 20), (18, 7), (83, 5), (150, 3)])  # > 64 (fwd) / > 32 (bwd): batch chunks in grid z
 def test_lstm_skip_matches_torch_lstm(B, T, dtype):
     """ga_lstm_fwd / ga_lstm_bwd (fused two-layer step kernels) against torch.nn.LSTM on the CPU."""
     torch.manual_seed(10)

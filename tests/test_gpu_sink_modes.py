@@ -19,7 +19,7 @@ def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
     torch.manual_seed(44)
     G0 = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="fp32").to(DEV).train()
     D0 = MultiScaleWaveDiscriminator(2, precision="fp32").to(DEV).train()
-    codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="fp32")
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="fp32")
     B, Tn = 2, 12
     q = 0.5 * torch.randn(B, 128, Tn, device=DEV)
     zc, zs, nz = torch.randn(B, 128, device=DEV), torch.randn(B, 128, device=DEV), torch.randn(B, 32, device=DEV)

@@ -83,7 +83,7 @@ def test_train_codec_stage_with_style_judge(tmp_path):
                 "z_style": torch.from_numpy(zs[i:i + bs]), "genre_idx": torch.from_numpy(gi[i:i + bs])} for i in range(0, n, bs)]
     G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(dev).train()
     D = MultiScaleWaveDiscriminator(2, precision="bf16").to(dev).train()
-    codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="bf16")
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
     judge = CodecStyleJudge(128, n_genres, hidden=64, emb_dim=128, precision="bf16").to(dev)
     before = {k: v.clone() for k, v in judge.state_dict().items()}
     cfg = CodecStageTrainConfig(stage_name="stage2", epochs=1, style_loss_mode="codec_judge_ce", style_embed_align_weight=0.5,

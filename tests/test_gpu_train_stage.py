@@ -35,7 +35,7 @@ def test_train_codec_stage_runs_checkpoints_and_resumes(tmp_path, prefetch):
     batches, q, zs, gi = _loader(6, T, n_genres, 2, seed=1)
     G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(dev).train()
     D = MultiScaleWaveDiscriminator(2, precision="bf16").to(dev).train()
-    codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="bf16")
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
     cfg = CodecStageTrainConfig(stage_name="stage2", epochs=2, d_step_period=2, r1_gamma=1.0, r1_interval=2,
                                 weights=CodecTrainWeights(content=0.0, style=0.0, mode_seeking=0.1))
     kw = dict(lab1_encoder=None, style_judge=None, train_loader=batches, n_genres=n_genres,
@@ -83,7 +83,7 @@ def test_train_codec_stage_from_a_codec_cache_on_disk(tmp_path):
     assert len(loader) == n // bs
     G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(dev).train()
     D = MultiScaleWaveDiscriminator(2, precision="bf16").to(dev).train()
-    codec = FrozenEncodec(decoder_state_dict=None, device="cuda", precision="bf16")
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
     cfg = CodecStageTrainConfig(stage_name="stage2", epochs=2, d_step_period=1, r1_gamma=0.0,
                                 weights=CodecTrainWeights(content=0.0, style=0.0))
     zs, gi = arr["z_style"], arr["genre_idx"]
@@ -94,3 +94,92 @@ def test_train_codec_stage_from_a_codec_cache_on_disk(tmp_path):
     assert len(rows) == 2 and all(set(r) == ROW_KEYS for r in rows)
     assert all(np.isfinite(r["loss_g"]) and np.isfinite(r["loss_d"]) for r in rows)
     assert rows[0]["d_steps_taken"] == len(loader) and loader.epoch == 2
+
+
+class _StubLab1:
+    """Stands in for the reference's FrozenLab1Encoder (lab3_bridge.py:159-234): `.cfg.sample_rate` and a differentiable
+    `forward_log_mel_tensor([B, 96, T]) -> {"z_content", "z_style"}`; a small frozen torch module, as the real one is."""
+
+    class _Cfg:
+        sample_rate = 22050
+
+    def __init__(self, device):
+        torch.manual_seed(5)
+        self.cfg = self._Cfg()
+        self.model = torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, stride=2, padding=1), torch.nn.ReLU(),
+                                         torch.nn.AdaptiveAvgPool2d((1, 1)), torch.nn.Flatten(), torch.nn.Linear(8, 256)).to(device)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.calls = 0
+
+    def forward_log_mel_tensor(self, log_mel):
+        assert log_mel.shape[1:] == (96, 256) and log_mel.is_cuda
+        self.calls += 1
+        h = self.model(log_mel.unsqueeze(1) / 80.0)
+        return {"z_content": torch.nn.functional.normalize(h[:, :128], dim=-1),
+                "z_style": torch.nn.functional.normalize(h[:, 128:], dim=-1)}
+
+
+@pytest.mark.parametrize("stage,mode", [("stage1", "lab1_cos"), ("stage2", "lab1_cos"), ("stage2", "codec_judge_ce")])
+def test_train_codec_stage_takes_the_reference_callers_arguments(tmp_path, stage, mode):
+    """The reference always passes a Lab1 encoder and defaults to style_loss_mode 'lab1_cos' with content weight 2.0 and
+    style weight 3.0 (run_lab3_codec.py:1282, lab3_codec_models.py:218-229): the stage must run that call and produce live
+    content / style terms whose gradient reaches the generator."""
+    from gan_amd.lab3_codec_judge import CodecStyleJudge
+    torch.manual_seed(328)
+    dev = torch.device("cuda")
+    n_genres, T = 3, 75   # 1 s clips: 24000 samples -> 22050 after the resample -> 87 mel frames, padded to 256
+    batches, q, zs, gi = _loader(4, T, n_genres, 2, seed=2)
+    G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(dev).train()
+    D = MultiScaleWaveDiscriminator(2, precision="bf16").to(dev).train()
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
+    lab1 = _StubLab1(dev)
+    judge = CodecStyleJudge(128, n_genres, hidden=32, emb_dim=128, precision="bf16").to(dev) if mode == "codec_judge_ce" else None
+    cfg = CodecStageTrainConfig(stage_name=stage, epochs=1, style_loss_mode=mode, weights=CodecTrainWeights())  # default weights
+    before = [p.detach().clone() for p in G.parameters()]
+    rows = train_codec_stage(cfg, G, D, codec, lab1, judge, batches, n_genres, build_style_centroid_bank(zs, gi, n_genres),
+                             build_style_exemplar_bank(zs, gi, n_genres), build_q_exemplar_bank(q, gi, n_genres), tmp_path, dev)
+    assert len(rows) == 1 and set(rows[0]) == ROW_KEYS
+    r = rows[0]
+    assert all(np.isfinite(v) for k, v in r.items() if k != "stage")
+    assert lab1.calls == 2 and 0.0 < r["loss_content"] <= 2.0 and r["loss_style"] > 0.0
+    if stage == "stage2":
+        assert r["loss_style_push"] >= 0.0
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, G.parameters()))
+
+
+def test_train_codec_stage_refuses_silently_dropped_terms(tmp_path):
+    dev = torch.device("cuda")
+    batches, q, zs, gi = _loader(2, 16, 2, 2, seed=3)
+    G = CodecLatentTranslator(hidden_channels=64, n_blocks=2, precision="bf16").to(dev)
+    D = MultiScaleWaveDiscriminator(2, precision="bf16").to(dev)
+    codec = FrozenEncodec(random_init=True, device="cuda", precision="bf16")
+    cfg = CodecStageTrainConfig(stage_name="stage1", epochs=1)  # default weights: content 2.0, style 3.0
+    with pytest.raises(ValueError, match="lab1_encoder is None"):
+        train_codec_stage(cfg, G, D, codec, None, None, batches, 2, build_style_centroid_bank(zs, gi, 2),
+                          build_style_exemplar_bank(zs, gi, 2), build_q_exemplar_bank(q, gi, 2), tmp_path, dev)
+
+
+def test_lab1_adapter_shapes_and_gradient():
+    """Lab1WaveAdapter (restated torchaudio pipeline, parity unpinned): output geometry of the reference (:210-221), the
+    -80 dB floor relative to the batch maximum, and a gradient that reaches the waveform."""
+    from gan_amd.lab1_adapter import Lab1WaveAdapter
+    dev = torch.device("cuda")
+    ad = Lab1WaveAdapter(24000, 22050, 256, dev)
+    torch.manual_seed(0)
+    x = (0.1 * torch.randn(2, 1, 120000, device=dev)).requires_grad_(True)
+    m = ad(x)
+    assert m.shape == (2, 96, 256) and torch.isfinite(m).all()
+    assert float(m.max() - m.min()) <= 80.0 + 1e-3
+    m.sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+    short = ad(0.1 * torch.randn(2, 1, 24000, device=dev))      # 1 s: 87 frames, right-padded with -80
+    assert short.shape == (2, 96, 256) and float(short[:, :, 87:].max()) == -80.0
+    # a 1 kHz tone at 24 kHz stays a 1 kHz tone at 22.05 kHz: the mel band around 1 kHz dominates
+    t = torch.arange(120000, device=dev) / 24000.0
+    tone = torch.sin(2 * torch.pi * 1000.0 * t)[None, None]
+    mt = ad(tone)[0].mean(dim=1)
+    import math
+    mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    want = (mel(1000.0) - mel(20.0)) / (mel(11025.0) - mel(20.0)) * 97 - 1
+    assert abs(int(mt.argmax()) - want) <= 1.0
