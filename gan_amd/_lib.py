@@ -71,12 +71,13 @@ class WgradParams(C.Structure):
 
 class LstmParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "bias2", "xg1", "x_in", "y", "h1", "h2", "c1", "c2", "gates1", "gates2",
-                                          "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype", "B_save")]
+                                          "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype", "B_save")] + \
+               [("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class LstmBwdParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1t", "w2t", "dy", "gates1", "gates2", "cs1", "cs2", "dg1", "dg2", "dc1", "dc2")] + \
-               [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype")]
+               [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype")] + [("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -120,7 +121,7 @@ _SIGNATURES = {
     "ga_grad_sqnorm": [_P, _Z, _P, _P],
     "ga_adamw_fused": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _P],
 }
-EXPORTED = sorted(list(_SIGNATURES) + ["ga_packed_elems", "ga_build_target"])
+EXPORTED = sorted(list(_SIGNATURES) + ["ga_packed_elems", "ga_build_target", "ga_lstm_persist_workspace_bytes"])
 
 _lib = None
 
@@ -142,6 +143,8 @@ def lib():
         l.ga_packed_elems.argtypes = [_I, _I, _I, _I, _I]
         l.ga_packed_elems.restype = C.c_size_t
         l.ga_wgrad_workspace_elems.restype = C.c_size_t
+        l.ga_lstm_persist_workspace_bytes.argtypes = [_I]
+        l.ga_lstm_persist_workspace_bytes.restype = C.c_size_t
         l.ga_build_target.argtypes = []
         l.ga_build_target.restype = C.c_char_p
         _lib = l

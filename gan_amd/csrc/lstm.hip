@@ -495,15 +495,24 @@ static void launch_bwd_fast(const ga_lstm_bwd_params& p, int st, hipStream_t s) 
 }
 
 // ------------------------------------------------------------------------------------------------
+int ga_lstm_fwd_persist(const ga_lstm_params& p, hipStream_t s);
+int ga_lstm_bwd_persist(const ga_lstm_bwd_params& p, hipStream_t s);
+
 extern "C" {
 
 int ga_lstm_fwd(const ga_lstm_params* hp, hipStream_t s) {
     if (!hp) return GA_ERR_ARG;
     const ga_lstm_params& p = *hp;
-    if (!p.w1 || !p.w2 || !p.bias2 || !p.xg1 || !p.x_in || !p.y || !p.h1 || !p.h2 || !p.c1 || !p.c2) return GA_ERR_ARG;
+    if (!p.w1 || !p.w2 || !p.bias2 || !p.xg1 || !p.x_in || !p.y) return GA_ERR_ARG;
     if (p.B <= 0 || p.T <= 0 || p.H <= 0 || p.H % 64) return GA_ERR_ARG;
     if ((p.gates1 == nullptr) != (p.gates2 == nullptr) || (p.gates1 && (!p.cs1 || !p.cs2))) return GA_ERR_ARG;
-    if (((uintptr_t)p.w1 | (uintptr_t)p.w2 | (uintptr_t)p.h1 | (uintptr_t)p.h2) & 15) return GA_ERR_ALIGN;
+    if (((uintptr_t)p.w1 | (uintptr_t)p.w2) & 15) return GA_ERR_ALIGN;
+    if (p.ws) {  // one persistent launch (lstm_persist.hip) when it applies
+        const int rc = ga_lstm_fwd_persist(p, s);
+        if (rc != GA_ERR_UNSUPPORTED) return rc;
+    }
+    if (!p.h1 || !p.h2 || !p.c1 || !p.c2) return GA_ERR_ARG;
+    if (((uintptr_t)p.h1 | (uintptr_t)p.h2) & 15) return GA_ERR_ALIGN;
     const dim3 grid(p.H / 4, 2);
     for (int st = 0; st <= p.T; ++st) {
         if (p.H == 512 && p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)
@@ -524,9 +533,15 @@ int ga_lstm_fwd(const ga_lstm_params* hp, hipStream_t s) {
 int ga_lstm_bwd(const ga_lstm_bwd_params* hp, hipStream_t s) {
     if (!hp) return GA_ERR_ARG;
     const ga_lstm_bwd_params& p = *hp;
-    if (!p.w1t || !p.w2t || !p.dy || !p.gates1 || !p.gates2 || !p.cs1 || !p.cs2 || !p.dg1 || !p.dg2 || !p.dc1 || !p.dc2) return GA_ERR_ARG;
+    if (!p.w1t || !p.w2t || !p.dy || !p.gates1 || !p.gates2 || !p.cs1 || !p.cs2 || !p.dg1) return GA_ERR_ARG;
     if (p.B <= 0 || p.T <= 0 || p.H <= 0 || p.H % 64) return GA_ERR_ARG;
-    if (((uintptr_t)p.w1t | (uintptr_t)p.w2t | (uintptr_t)p.dg1 | (uintptr_t)p.dg2) & 15) return GA_ERR_ALIGN;
+    if (((uintptr_t)p.w1t | (uintptr_t)p.w2t | (uintptr_t)p.dg1) & 15) return GA_ERR_ALIGN;
+    if (p.ws) {
+        const int rc = ga_lstm_bwd_persist(p, s);
+        if (rc != GA_ERR_UNSUPPORTED) return rc;
+    }
+    if (!p.dg2 || !p.dc1 || !p.dc2) return GA_ERR_ARG;
+    if ((uintptr_t)p.dg2 & 15) return GA_ERR_ALIGN;
     const dim3 grid(p.H / 16, 2);
     for (int st = 0; st <= p.T; ++st) {
         if (p.H == 512 && p.w_dtype == GA_DTYPE_BF16 && p.act_dtype == GA_DTYPE_BF16)

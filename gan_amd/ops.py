@@ -1195,6 +1195,26 @@ class StftSums(torch.autograd.Function):
 
 
 # ================================================================================================
+LSTM_PERSIST = True  # bf16, H = 512: one persistent launch per pass (lstm_persist.hip); tests switch it off to compare
+_LSTM_WS: dict = {}
+
+
+def _lstm_workspace(device) -> Tensor:
+    """The persistent LSTM kernels' exchange buffer + counters, one per (device, stream): calls on one stream are ordered."""
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _LSTM_WS.get(key)
+    if ws is None:
+        n = int(L.lib().ga_lstm_persist_workspace_bytes(0))
+        ws = _LSTM_WS[key] = torch.zeros((n,), device=device, dtype=torch.uint8)
+    return ws
+
+
+def lstm_persist_error(device=None) -> bool:
+    """True when a persistent LSTM launch on this device raised its error word (a bounded wait ran out).  Synchronises."""
+    return any(bool(ws[:4].view(torch.int32).item()) for (d, _), ws in _LSTM_WS.items() if device is None or d == torch.device(device))
+
+
 class LstmSkip(torch.autograd.Function):
     """y = LSTM2(x) + x for the frozen decoder (HF EncodecLSTM); x, y: [B, T, H] channels-last.
     `w` is the dict prepared by prepare_lstm_weights (frozen, cached by the decoder)."""
@@ -1222,6 +1242,9 @@ class LstmSkip(torch.autograd.Function):
         gates = torch.empty((2, Bg, T, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
         cs = torch.empty((2, Bg, T, H), device=dev, dtype=torch.float32) if need_grad else None
         p = L.LstmParams()
+        if LSTM_PERSIST and dtype == torch.bfloat16 and H == 512:
+            ws = _lstm_workspace(dev)
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel()
         _fill(p, w1=w["hh0"].data_ptr(), w2=w["cat1"].data_ptr(), bias2=w["bias2"].data_ptr(), xg1=xg1.data_ptr(),
               x_in=x.data_ptr(), y=y.data_ptr(), h1=h1.data_ptr(), h2=h2.data_ptr(), c1=c[0].data_ptr(), c2=c[1].data_ptr(),
               gates1=L.ptr(gates[0]) if need_grad else 0, gates2=L.ptr(gates[1]) if need_grad else 0,
@@ -1246,6 +1269,9 @@ class LstmSkip(torch.autograd.Function):
         dg = torch.empty((2, B, T, 4 * H), device=dev, dtype=dtype)
         dc = zeros_f32(2 * B * H, dev).view(2, B, H)
         p = L.LstmBwdParams()
+        if LSTM_PERSIST and dtype == torch.bfloat16 and H == 512:
+            ws = _lstm_workspace(dev)
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel()
         _fill(p, w1t=w["hh0_t"].data_ptr(), w2t=w["cat1_t"].data_ptr(), dy=dy.data_ptr(), gates1=gates[0].data_ptr(),
               gates2=gates[1].data_ptr(), cs1=cs[0].data_ptr(), cs2=cs[1].data_ptr(), dg1=dg[0].data_ptr(), dg2=dg[1].data_ptr(),
               dc1=dc[0].data_ptr(), dc2=dc[1].data_ptr(), B=B, T=T, H=H, act_dtype=L.dt(dy), w_dtype=L.dt(dg))

@@ -325,8 +325,15 @@ typedef struct ga_lstm_params {
     float* cs1; float* cs2;       /* [B][T][H] or NULL */
     int B, T, H, act_dtype, w_dtype;
     int B_save; /* gates / cell states are recorded for batch items [0, B_save) only; <= 0 means all B */
+    void* ws;        /* optional (bf16, H = 512): workspace of ga_lstm_persist_workspace_bytes() bytes, 256-byte aligned.  With
+                        it the pass runs as ONE persistent launch (lstm_persist.hip: recurrent weights resident in LDS, hidden
+                        state exchanged between workgroups through ws with write-through stores and a counter) instead of T+1
+                        step launches; h1 / h2 / c1 / c2 are then not written.  The first word of ws is an error flag the
+                        kernel raises when a bounded wait ran out (results invalid); calls sharing one ws must not overlap. */
+    size_t ws_bytes;
 } ga_lstm_params;
 int ga_lstm_fwd(const ga_lstm_params* h_params, ga_stream_t stream);
+size_t ga_lstm_persist_workspace_bytes(int B);
 /* backward w.r.t. the input only (weights are frozen): fills dg1 = d(loss)/d(gate pre-activations of layer 1) for all
  * steps; dx = dg1 @ weight_ih_l0 + dy is one more ga_conv (k=1, residual epilogue).
  *   w1t = weight_hh_l0^T [H][4H]; w2t = [weight_ih_l1^T ; weight_hh_l1^T] [2H][4H]; dc1, dc2 [B][H] zeroed by the caller */
@@ -337,6 +344,8 @@ typedef struct ga_lstm_bwd_params {
     void* dg1; void* dg2; /* [B][T][4H] w dtype */
     float* dc1; float* dc2;
     int B, T, H, act_dtype, w_dtype;
+    void* ws;        /* optional, as in ga_lstm_params: one persistent launch; dg2 / dc1 / dc2 are then not written */
+    size_t ws_bytes;
 } ga_lstm_bwd_params;
 int ga_lstm_bwd(const ga_lstm_bwd_params* h_params, ga_stream_t stream);
 

@@ -808,9 +808,15 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("B,T", [(3, 20), (18, 7), (83, 5), (150, 3)])  # > 64 (fwd) / > 32 (bwd): batch chunks in grid z
-def test_lstm_skip_matches_torch_lstm(B, T, dtype):
-    """ga_lstm_fwd / ga_lstm_bwd (fused two-layer step kernels) against torch.nn.LSTM on the CPU."""
+@pytest.mark.parametrize("persist", [True, False], ids=["persistent", "steps"])
+@pytest.mark.parametrize("B,T", [(3, 20), (18, 7), (83, 5), (150, 3), (36, 40), (270, 4)])  # > 64 (fwd) / > 32 (bwd): batch chunks in grid z
+def test_lstm_skip_matches_torch_lstm(B, T, dtype, persist, monkeypatch):
+    """ga_lstm_fwd / ga_lstm_bwd against torch.nn.LSTM on the CPU: the chain of fused two-layer step launches (lstm.hip) and,
+    in bf16, the persistent kernels with the weights resident in LDS (lstm_persist.hip; several groups, ragged last tile,
+    more than one launch at B = 270)."""
+    if persist and dtype != torch.bfloat16:
+        pytest.skip("the persistent LSTM kernels are bf16 only")
+    monkeypatch.setattr(ops, "LSTM_PERSIST", persist)
     torch.manual_seed(10)
     H = 512
     lstm = torch.nn.LSTM(H, H, 2)
@@ -831,3 +837,4 @@ def test_lstm_skip_matches_torch_lstm(B, T, dtype):
     close(gx, gx_ref, tol, "lstm bwd")
     with torch.no_grad():  # inference path (no saved gates)
         close(ops.LstmSkip.apply(x.to(DEV, dtype), w), y_ref, tol, "lstm fwd nograd")
+    assert not ops.lstm_persist_error()

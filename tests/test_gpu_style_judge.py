@@ -96,11 +96,10 @@ def test_train_codec_stage_with_style_judge(tmp_path):
     assert r["loss_style"] > 0.5 and r["loss_style_embed"] > 0.0 and r["loss_style_push"] > 0.0 and np.isfinite(r["loss_g"])
     assert not judge.training and all(not p.requires_grad and p.grad is None for p in judge.parameters())
     assert all(torch.equal(v, before[k]) for k, v in judge.state_dict().items())
-    # another mode leaves the style terms at zero, as the reference does
+    # a mode that needs the Lab1 encoder, with a nonzero style weight and no encoder: refused (it would silently drop the term)
     cfg.style_loss_mode = "lab1_cos"
-    with pytest.warns(UserWarning):
-        rows = train_codec_stage(cfg, G, D, codec, lab1_encoder=None, style_judge=judge, train_loader=batches, n_genres=n_genres,
-                                 style_centroid_bank=build_style_centroid_bank(zs, gi, n_genres),
-                                 style_exemplar_bank=build_style_exemplar_bank(zs, gi, n_genres),
-                                 q_exemplar_bank=build_q_exemplar_bank(q, gi, n_genres), out_ckpt_dir=tmp_path, device=dev)
-    assert rows[0]["loss_style"] == 0.0 and rows[0]["loss_style_push"] == 0.0
+    with pytest.raises(ValueError, match="lab1_encoder is None"):
+        train_codec_stage(cfg, G, D, codec, lab1_encoder=None, style_judge=judge, train_loader=batches, n_genres=n_genres,
+                          style_centroid_bank=build_style_centroid_bank(zs, gi, n_genres),
+                          style_exemplar_bank=build_style_exemplar_bank(zs, gi, n_genres),
+                          q_exemplar_bank=build_q_exemplar_bank(q, gi, n_genres), out_ckpt_dir=tmp_path, device=dev)
