@@ -84,3 +84,59 @@ def test_sharded_loader_covers_each_epoch_once_across_ranks():
     assert ld.epoch == 1
     with pytest.raises(ValueError):
         ShardedCodecLoader(ds, bs, rank=2, world_size=2)
+
+
+# ---- wire-format parity against a cache the REFERENCE wrote (tests/golden/make_golden_cache.py) ---------------------------
+GOLD = __import__("pathlib").Path(__file__).resolve().parent / "golden"
+
+
+def _fixture_arrays():
+    """The procedural content make_golden_cache.py handed to the reference's save_codec_cache."""
+    from oracle.procfill import proc_input
+    N, T = 5, 16
+    codes = (proc_input((N, 8, T), "cache.codes", 0, 1.0).numpy() * 300.0 + 512.0).clip(0, 1023).astype(np.int16)
+    return {"q_emb": proc_input((N, 128, T), "cache.q_emb", 0, 0.9).numpy(), "codes": codes,
+            "z_content": proc_input((N, 128), "cache.zc", 0).numpy(), "z_style": proc_input((N, 128), "cache.zs", 0).numpy(),
+            "genre_idx": np.array([0, 1, 2, 1, 0], dtype=np.int64), "mert_feat": proc_input((N, 768), "cache.mert", 0).numpy()}
+
+
+def test_loads_a_cache_written_by_the_reference():
+    """load_codec_cache / CachedCodecDataset / build_genre_exemplar_index on the reference-written fixture give what the
+    reference's own loader returned for it (recorded in ref_cache_manifest.json) and the arrays that went in."""
+    man = json.loads((GOLD / "ref_cache_manifest.json").read_text())
+    index_df, arrays, gmap, meta = load_codec_cache(GOLD / "ref_cache")
+    want = _fixture_arrays()
+    assert set(arrays) == set(man["loaded"]) == set(want)
+    for k, rec in man["loaded"].items():
+        assert str(arrays[k].dtype) == rec["dtype"] and list(arrays[k].shape) == rec["shape"], k
+        assert float(np.asarray(arrays[k], dtype=np.float64).sum()) == pytest.approx(rec["sum"], rel=1e-12, abs=1e-9), k
+        np.testing.assert_array_equal(arrays[k], want[k])
+    assert gmap == man["genre_to_idx"]
+    assert meta.__dict__ == man["meta"]
+    assert list(index_df.columns) == man["index_columns"] and len(index_df) == man["index_rows"]
+    ds = CachedCodecDataset(arrays, np.array([3, 0, 4]))
+    assert len(ds) == man["dataset_len"]
+    item = ds[1]
+    assert set(item) == set(man["dataset_item1"])
+    for k, rec in man["dataset_item1"].items():
+        assert str(item[k].dtype) == rec["dtype"] and list(item[k].shape) == rec["shape"], k
+        assert float(item[k].double().sum()) == pytest.approx(rec["sum"], rel=1e-12, abs=1e-9), k
+    ex = build_genre_exemplar_index(arrays["genre_idx"])
+    assert {str(k): v.tolist() for k, v in ex.items()} == man["exemplar_index"]
+
+
+def test_writes_the_files_the_reference_writes(tmp_path):
+    """The reverse direction: save_codec_cache on the same content produces the reference's files - same names, the same npz
+    members with the same dtypes and shapes and values, byte-identical JSON files and index CSV."""
+    import pandas as pd
+    man = json.loads((GOLD / "ref_cache_manifest.json").read_text())
+    ref_index = pd.read_csv(GOLD / "ref_cache" / "codec_cache_index.csv")
+    save_codec_cache(tmp_path, ref_index, _fixture_arrays(), man["genre_to_idx"], CodecCacheMeta(**man["meta"]))
+    assert sorted(p.name for p in tmp_path.iterdir()) == man["files"]
+    with np.load(tmp_path / "codec_cache_arrays.npz") as z, np.load(GOLD / "ref_cache" / "codec_cache_arrays.npz") as r:
+        assert sorted(z.files) == sorted(r.files) == sorted(man["npz_on_disk"])
+        for k, rec in man["npz_on_disk"].items():
+            assert str(z[k].dtype) == rec["dtype"] and list(z[k].shape) == rec["shape"], k
+            np.testing.assert_array_equal(z[k], r[k])
+    for name in ("codec_genre_to_idx.json", "codec_meta.json", "codec_cache_index.csv"):
+        assert (tmp_path / name).read_bytes() == (GOLD / "ref_cache" / name).read_bytes(), name
