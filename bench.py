@@ -53,24 +53,51 @@ def make_batch(B: int, T: int, device, gen: torch.Generator):
     return [t.to(device) for t in (q_src, zc, zs, noise, bank[idx_d], bank[idx_g])]
 
 
-def cpu_baseline(T: int, sample_B: int, iters: int):
-    """The CPU oracle (oracle/codec_oracle.py, a torch-CPU port of the reference step) timed on the host cores."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(T: int, batches=(4, 12), iters: int = 5, budget_s: float = 75.0):
+    """The CPU oracle (oracle/codec_oracle.py, a torch-CPU port of the reference step pinned against the reference's own
+    outputs) timed on the host cores, SURVEY.md 8(d): B = 4 and B = 12, one warm-up + up to `iters` iterations each, median,
+    all the cores this job may use, CPU model stated.  Bounded: a leg stops taking iterations once `budget_s` seconds are
+    spent (at least two timed iterations), and says how many it took."""
+    import statistics
     from oracle import codec_oracle as O
     n_threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(n_threads)
-    g_sd, d_sd, dec_sd = O.fresh_state()
-    gen = torch.Generator().manual_seed(328)
     cfg = O.StepCfg(weights=O.Weights(content=0.0, style=0.0))
-    og, od = O.AdamWState(), O.AdamWState()
-    batch = [t.cpu() for t in make_batch(sample_B, T, "cpu", gen)]
-    O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 1, cfg)  # warm-up
-    t0 = time.perf_counter()
-    for i in range(iters):
-        O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 2 + i, cfg)
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": round(sample_B / dt, 4), "unit": "samples/s", "cores": n_threads, "kind": "port",
-            "sample": f"{iters} iterations of the same step at B={sample_B}, T={T} (S={T*320}), fp32, after 1 warm-up; "
-                      f"{dt:.2f} s/iteration"}
+    t_start = time.perf_counter()
+    legs = {}
+    for bi, B in enumerate(batches):
+        g_sd, d_sd, dec_sd = O.fresh_state()
+        gen = torch.Generator().manual_seed(328)
+        og, od = O.AdamWState(), O.AdamWState()
+        batch = [t.cpu() for t in make_batch(B, T, "cpu", gen)]
+        O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 1, cfg)  # warm-up
+        times = []
+        share = budget_s * (bi + 1) / len(batches)
+        for i in range(iters):
+            t0 = time.perf_counter()
+            O.iteration(g_sd, d_sd, dec_sd, og, od, batch, 2 + i, cfg)
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 2 and time.perf_counter() - t_start > share:
+                break
+        legs[B] = (statistics.median(times), len(times))
+    B_main = batches[-1]
+    return {"value": round(B_main / legs[B_main][0], 4), "unit": "samples/s", "cores": n_threads, "kind": "port",
+            "cpu_model": _cpu_model(),
+            "by_batch": {str(B): {"samples_per_s": round(B / dt, 4), "s_per_iteration": round(dt, 3), "iterations": n}
+                         for B, (dt, n) in legs.items()},
+            "sample": f"oracle.codec_oracle.iteration (torch CPU, fp32) on the same step at T={T} (S={T*320}): B=" +
+                      " and B=".join(f"{B} (median of {n} iterations after 1 warm-up, {dt:.2f} s each)" for B, (dt, n) in legs.items())
+                      + f"; {n_threads} threads; value = B={B_main}"}
 
 
 def pmc_traffic(kernel_name):
@@ -98,12 +125,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=12, help="samples per GPU (reference default batch size, run_lab3_codec.py:201)")
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU: SURVEY.md 8(d) config 2 sweeps {12, 64, 256, max-fit}; 64 is "
+                    "the headline, and the reference's default 12 (run_lab3_codec.py:201) is measured too and reported under 'batch12'")
+    ap.add_argument("--no-batch12", action="store_true", help="skip the second measurement at the reference's default batch of 12")
     ap.add_argument("--frames", type=int, default=375, help="latent frames T (5 s x 75 Hz); S = 320*T samples")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     ap.add_argument("--prefetch", action="store_true", help="decode the next batch's frozen latents one iteration ahead on a side "
                     "stream (gan_amd/prefetch.py; measured slower on MI355X: the two launch-bound chains do not overlap)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
@@ -146,13 +175,16 @@ def main():
     if dp is not None:
         dp.broadcast_params(opt_g, opt_d)
     gen = torch.Generator().manual_seed(328 + rank)
-    batches = [make_batch(args.batch, args.frames, device, gen) for _ in range(2)]
 
     # optional (train_codec_stage(prefetch=True)): the next batch's frozen latents decoded on a side stream
     from gan_amd.prefetch import FrozenDecodePrefetcher
     prefetcher = FrozenDecodePrefetcher(codec) if args.prefetch else None
+    state = {"batches": None, "i": 0}
 
-    def step(i):
+    def step(_i=None):
+        i = state["i"]
+        state["i"] += 1
+        batches = state["batches"]
         b = batches[i % len(batches)]
         nb = batches[(i + 1) % len(batches)]
         return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp,
@@ -163,20 +195,31 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dp is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
-    loss_g = float(out["loss_g"])
-    assert loss_g == loss_g, "loss is NaN"
+    def measure(batch):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        state["batches"] = [make_batch(batch, args.frames, device, gen) for _ in range(2)]
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        el = time.perf_counter() - t0
+        if dp is not None:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t)
+        lg = float(out["loss_g"])
+        assert lg == lg, "loss is NaN"
+        return el, lg
+
+    batch12 = None
+    if args.batch != 12 and not args.no_batch12:  # the reference's default batch size, second line of the report
+        el12, _ = measure(12)
+        batch12 = {"batch_per_gpu": 12, "global_batch": 12 * world, "value": round(12 * world * args.steps / el12, 3),
+                   "unit": "samples/s", "ms_per_step": round(1e3 * el12 / args.steps, 3)}
+    elapsed, loss_g = measure(args.batch)
 
     # per-kernel accounting: one more step with HIP events (torch current stream == launch stream) around every
     # convolution launch; achieved = launched multiply-add flops / event time, per kernel.
@@ -184,27 +227,28 @@ def main():
     kernels = {}
     if rank == 0:
         ops.PROFILE = []
-        step(args.warmup + args.steps)
+        step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         if args.conv_table:
             rows = {}
-            for kid, flops, e0, e1, shape in prof:
+            for kid, _launched, e0, e1, shape, flops in prof:  # algorithmic flops
                 r = rows.setdefault((kid,) + shape, [0, 0.0, 0.0])
                 r[0] += 1; r[1] += flops; r[2] += e0.elapsed_time(e1)
             print("kernel  (B, Cin, M, J, Lout, nphase, in_stride, pre_act)  launches  ms  TFLOP/s", file=sys.stderr)
             for key, r in sorted(rows.items(), key=lambda kv: -kv[1][2]):
                 print(f"{KERNEL_NAMES[key[0]]:26s} {str(key[1:]):44s} {r[0]:3d} {r[2]:8.3f} {r[1] / max(r[2], 1e-9) / 1e9:8.1f}", file=sys.stderr)
         esz = 2 if args.precision == "bf16" else 4
-        for kid, flops, e0, e1, shape in prof:
-            k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
+        for kid, launched, e0, e1, shape, flops in prof:
+            k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "launched": 0.0, "ms": 0.0, "bytes": 0.0})
             k["launches"] += 1
             k["flops"] += flops
+            k["launched"] += launched
             k["ms"] += e0.elapsed_time(e1)
             b_, cin_, m_, j_, lout_, _nph, istr_ = shape[:7]
             # algorithmic bytes of one launch: the input window once, the packed weights once, the output once
             k["bytes"] += esz * (b_ * lout_ * max(1, istr_) * cin_ + m_ * j_ * cin_ + b_ * lout_ * m_)
-        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9)), key=lambda k: kernels[k]["ms"], default=None)
+        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9, 11)), key=lambda k: kernels[k]["ms"], default=None)
         if dom is not None:
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
@@ -212,6 +256,9 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                         "flops_per_launch_avg": k["flops"] / k["launches"],
+                        "launched_TFLOP/s": round(k["launched"] / (k["ms"] * 1e-3) / 1e12, 2),
+                        "flops": "algorithmic (conv taps k, DFT K once); launched_TFLOP/s counts the padded taps of strided "
+                                 "data gradients and the 3x-deep K of the bf16 hi/lo MR-STFT GEMM",
                         "algorithmic_bytes_per_launch_avg": k["bytes"] / k["launches"]}
             roofline.update(pmc_traffic(KERNEL_NAMES[dom]))
 
@@ -232,8 +279,10 @@ def main():
                                  for k, v in sorted(kernels.items())},
             "loss_g_last": round(loss_g, 5),
         }
+        if batch12 is not None:
+            line["batch12"] = batch12
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_sample_batch, args.cpu_iters)
+            line["cpu_baseline"] = cpu_baseline(args.frames, (4, 12), args.cpu_iters, args.cpu_budget_s)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dp is not None:

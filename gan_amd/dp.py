@@ -42,7 +42,8 @@ class _OverlapState:
 
     def __init__(self, dp: "DataParallel", opt):
         self.dp, self.opt = dp, opt
-        self.slices = dp.bucket_slices(opt.numel)
+        self.sink = None  # ops.WeightGradSink of the running backward pass (conv weights' gradients bypass p.grad)
+        self.slices = dp.bucket_slices_for(opt)
         self.bucket_of: List[List[int]] = []
         self.need = [0] * len(self.slices)
         for p, off in zip(opt.params, opt.offsets):
@@ -52,6 +53,11 @@ class _OverlapState:
             for b in bs:
                 self.need[b] += 1
         self.members = [[i for i, bs in enumerate(self.bucket_of) if b in bs] for b in range(len(self.slices))]
+        # buckets whose readiness parameter i counts towards: its own, plus - learnt from the sink's offers - those of its
+        # weight-norm partner (a layer's deferred gradient is finished for weight and gain together, so a bucket holding
+        # one of them must also wait for the other one's contributions)
+        self.dep_of: List[List[int]] = [list(bs) for bs in self.bucket_of]
+        self.pairs: set = set()
         self.copied: List[bool] = []
         self.cuda = opt.flat_g.is_cuda
         self.comm = torch.cuda.Stream(device=opt.flat_g.device) if self.cuda else None
@@ -60,8 +66,25 @@ class _OverlapState:
         self.sent: List[bool] = []
         self.works: list = []
 
-    def begin(self) -> None:
+    def learn_pair(self, iv: int, ig) -> None:
+        """sink.offer callback: layer (weight iv, gain ig) exists.  Runs before either parameter's hook of this pass."""
+        if ig is None or (iv, ig) in self.pairs:
+            return
+        self.pairs.add((iv, ig))
+        for a, other in ((iv, ig), (ig, iv)):
+            for bk in self.bucket_of[other]:
+                if bk not in self.dep_of[a]:
+                    self.dep_of[a].append(bk)
+                    self.need[bk] += 1
+                    if self.active:
+                        self.left[bk] += 1
+
+    def begin(self, sink=None) -> None:
+        self.sink = sink
+        if sink is not None:
+            sink.on_offer = self.learn_pair
         self.opt.flat_g.zero_()
+        self.arrived = [False] * len(self.opt.params)
         self.left = list(self.need)
         self.copied = [False] * len(self.opt.params)
         self.sent = [False] * len(self.slices)
@@ -69,9 +92,13 @@ class _OverlapState:
         self.active = True
 
     def on_grad(self, i: int) -> None:
-        if not self.active:
+        """Post-accumulate-grad hook of parameter i: every contribution of this pass to it has been produced.  (torch runs
+        the hook of a parameter whose incoming gradient is undefined too, which is what a conv weight whose gradient went
+        to the sink looks like to autograd; should a torch version not do that, such parameters simply wait for finish().)"""
+        if not self.active or self.arrived[i]:
             return
-        for b in self.bucket_of[i]:
+        self.arrived[i] = True
+        for b in self.dep_of[i]:
             self.left[b] -= 1
             if self.left[b] == 0:
                 self._send(b)
@@ -82,8 +109,20 @@ class _OverlapState:
         self.sent[b] = True
         # one fused copy of the bucket's gradients into the flat buffer.  A parameter that straddles two buckets is copied
         # with the first of them to go; the other one cannot have gone earlier, because it was waiting for this parameter too.
+        # Deferred conv-weight gradients (sink) whose weight or gain lies in this bucket are finished into the flat buffer by
+        # one launch; their partner parameter, if it lies in another bucket, is copied now as well so that the finish kernel's
+        # accumulate flags (a p.grad that existed before the pass, e.g. R1's, or a second use of the layer in this pass) see
+        # the value they add to.  The partner has arrived too: a bucket also waits for the partners of its members (dep_of).
+        members = list(self.members[b])
+        deferred = []
+        if self.sink is not None and self.sink.pending:
+            mset = set(members)
+            deferred = [iv for iv, ent in self.sink.pending.items() if iv in mset or (ent[0] is not None and ent[0] in mset)]
+            for iv in deferred:
+                ig = self.sink.pending[iv][0]
+                members += [i for i in (iv, ig) if i is not None and i not in mset]
         src, dst = [], []
-        for i in self.members[b]:
+        for i in members:
             if not self.copied[i]:
                 self.copied[i] = True
                 g = self.opt.params[i].grad
@@ -93,6 +132,8 @@ class _OverlapState:
         if src:
             with torch.no_grad():
                 torch._foreach_copy_(dst, src)
+        if deferred:
+            self.sink.flush(only=deferred)
         a, e = self.slices[b]
         chunk = self.opt.flat_g[a:e]
         if self.cuda:
@@ -108,13 +149,16 @@ class _OverlapState:
         self.active = False
         for b in range(len(self.slices)):
             self._send(b)
+        if self.sink is not None:
+            self.sink.on_offer = None
+        self.sink = None
         for w in self.works:
             w.wait()  # (RCCL: the current stream waits; no host synchronisation)
         self.works = []
 
 
 class DataParallel:
-    def __init__(self, group=None, bucket_bytes: int = 64 << 20, exact_stft: bool = True):
+    def __init__(self, group=None, bucket_bytes: int = 24 << 20, exact_stft: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -122,10 +166,10 @@ class DataParallel:
         self.world_size = dist.get_world_size(group)
         self.bucket_elems = max(1, int(bucket_bytes) // 4)
         self.exact_stft = exact_stft
-        # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward).  Off by default:
-        # measured on one MI355X (one-rank RCCL group, so the collective is a device copy) the side-stream collectives
-        # cost the backward pass 1.5 ms per iteration, more than the ~1 ms of xGMI all-reduce they could hide at 8 ranks.
-        self.overlap = False
+        # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward): the default as soon
+        # as there is more than one rank (north star: "all-reduce overlapped with the discriminator backward pass").  With one
+        # rank there is nothing to hide, and the side-stream collectives only cost launches.
+        self.overlap = self.world_size > 1
 
     def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
         """Contiguous [start, end) slices of the flat gradient buffer, last parameters first."""
@@ -137,10 +181,24 @@ class DataParallel:
             end = start
         return out
 
+    def bucket_slices_for(self, opt) -> List[Tuple[int, int]]:
+        """Buckets of one optimizer's flat gradient buffer in the order the backward pass completes them: parameters are
+        walked from the LAST one (D: scale 2 ... scale 0, each `out` -> blocks.4 -> ... -> blocks.0) and a
+        bucket is closed at a parameter boundary once it holds bucket_elems, so no tensor straddles two collectives."""
+        params, offsets = getattr(opt, "params", None), getattr(opt, "offsets", None)
+        if not params:
+            return self.bucket_slices(opt.numel)
+        out, end = [], opt.numel
+        for i in range(len(params) - 1, -1, -1):
+            if end - offsets[i] >= self.bucket_elems or i == 0:
+                out.append((0 if i == 0 else offsets[i], end))
+                end = offsets[i]
+        return out
+
     def allreduce_flat(self, opt) -> None:
         """SUM-all-reduce opt.flat_g bucket by bucket; the mean is applied inside the AdamW kernel."""
         works = []
-        for a, b in self.bucket_slices(opt.numel):
+        for a, b in self.bucket_slices_for(opt):
             works.append(dist.all_reduce(opt.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
@@ -160,9 +218,9 @@ class DataParallel:
         for i, p in enumerate(opt.params):
             p.register_post_accumulate_grad_hook(lambda _p, i=i, st=st: st.on_grad(i))
 
-    def begin_backward(self, opt) -> None:
+    def begin_backward(self, opt, sink=None) -> None:
         self.attach(opt)
-        opt._dp_overlap.begin()
+        opt._dp_overlap.begin(sink)
 
     def finish_backward(self, opt) -> None:
         opt._dp_overlap.finish()

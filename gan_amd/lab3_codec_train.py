@@ -227,8 +227,15 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
     module instead of unpack / weight-norm backward / copy per layer).  Under data parallelism the flat buffer is then
     all-reduced in buckets; with dp.overlap the buckets go out while the backward pass is still running (gan_amd/dp.py)."""
     if dp is not None and getattr(dp, "overlap", False):
-        dp.begin_backward(opt)
-        loss.backward()
+        # buckets go out from the parameters' post-accumulate-grad hooks, which run once per parameter after ALL of the
+        # pass's contributions to it (the sink's deferred one and, for a layer used twice, the p.grad one)
+        sink = ops.WeightGradSink(opt) if (ops.WGRAD_SINK and loss.is_cuda) else None
+        dp.begin_backward(opt, sink)
+        ops._SINK = sink
+        try:
+            loss.backward()
+        finally:
+            ops._SINK = None
         dp.finish_backward(opt)
         return
     sink = ops.WeightGradSink(opt) if (ops.WGRAD_SINK and loss.is_cuda) else None

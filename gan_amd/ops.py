@@ -114,7 +114,10 @@ def dgrad_params(g: ConvGeom, B: int, lin: int) -> L.ConvParams:
     return p
 
 
-def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, res=None, dact_src=None, impl=L.IMPL_AUTO):
+def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, res=None, dact_src=None, impl=L.IMPL_AUTO,
+                 alg_flops: Optional[float] = None):
+    """alg_flops: the ALGORITHMIC multiply-add flops of this launch when they differ from the launched ones (a strided data
+    gradient runs ceil(k/s)*s taps for k, the bf16 MR-STFT GEMM runs a 3x-deep K for its hi/lo split); benchmark accounting."""
     L.require_cuda(x, w, y)
     assert x.is_contiguous() and w.is_contiguous() and y.is_contiguous()
     assert x.dtype == w.dtype, (x.dtype, w.dtype)
@@ -155,8 +158,9 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
     if ks > 1:
         L.check(L.lib().ga_conv_finish(C.byref(p), L.dt(x), L.stream()), "ga_conv_finish")
     e1.record()
-    PROFILE.append((kid, 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin, e0, e1,
-                    (p.B, p.Cin, p.M, p.J, p.Lout, p.nphase, p.in_stride, p.pre_act)))
+    launched = 2.0 * p.B * p.nphase * p.Lout * p.M * p.J * p.Cin
+    PROFILE.append((kid, launched, e0, e1, (p.B, p.Cin, p.M, p.J, p.Lout, p.nphase, p.in_stride, p.pre_act),
+                    launched if alg_flops is None else float(alg_flops)))
 
 
 _BIAS_REP: dict = {}
@@ -263,7 +267,8 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
         assert g.kind == "conv" and res is not None and dact_src is not None and dact_mode
         p.res_mode, p.res_coef, p.res_coef_dev = L.RES_FM_SIGN, float(fm_coef[0]), fm_coef[1].data_ptr()
     dx = torch.empty((B, lin, g.cin), device=gy.device, dtype=gy.dtype)
-    _launch_conv(p, gy, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL)
+    alg = 2.0 * B * g.out_len(lin) * g.cout * g.cin * g.k if (g.kind == "conv" and g.stride > 1) else None
+    _launch_conv(p, gy, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL, alg_flops=alg)
     if g.kind == "cconv" and g.k > 1:
         # fold the gradient of the reflected left pad back: dx[l] += dxp[-l], l = 1..P   (in_stride = -1)
         P = min((g.k - 1) * g.dilation, lin - 1)
@@ -420,6 +425,7 @@ class WeightGradSink:
             m = opt._sink_map = {p.data_ptr(): i for i, p in enumerate(opt.params)}
         self.index = m
         self.pending = {}
+        self.on_offer = None  # dp._OverlapState.learn_pair: told (index of v, index of g | None) of every layer that arrives
 
     def offer(self, v, gparam, norm, geom, gpacked) -> bool:
         d0, d1, k = geom.wdims
@@ -430,12 +436,18 @@ class WeightGradSink:
         if iv is None or (gparam is not None and ig is None) or iv in self.pending:
             return False
         self.pending[iv] = (ig, v, gparam, norm, (d0, d1, k), gpacked.contiguous())
+        if self.on_offer is not None:
+            self.on_offer(iv, ig)
         return True
 
-    def flush(self) -> None:
-        """after opt.gather_grads(): add (p.grad present: it has been copied in) or write (absent) the deferred gradients"""
-        todo = list(self.pending.items())
-        self.pending = {}
+    def flush(self, only=None) -> None:
+        """after opt.gather_grads(): add (p.grad present: it has been copied in) or write (absent) the deferred gradients.
+        `only`: finish just these layers (indices of their weights) - the overlapped all-reduce sends bucket by bucket."""
+        if only is None:
+            todo = list(self.pending.items())
+            self.pending = {}
+        else:
+            todo = [(iv, self.pending.pop(iv)) for iv in only if iv in self.pending]
         opt, lib = self.opt, L.lib()
         for c0 in range(0, len(todo), L.PACK_MULTI_MAX):
             chunk = todo[c0:c0 + L.PACK_MULTI_MAX]
@@ -1164,7 +1176,8 @@ class StftSums(torch.autograd.Function):
             p = _new_params()
             _fill(p, B=B, Lin=rows, Cin=hop * rep, M=M, Lout=frames, LoutTot=frames, J=J, off0=0, out_f32=1 if split else 0)
             spec = torch.empty((B, frames, M), device=x.device, dtype=torch.float32)
-            _launch_conv(p, xp, w_f, spec, impl=_IMPL)
+            # algorithmic work of the DFT-basis GEMM: frames x n_fft x 2*(n_fft/2+1) multiply-adds, once (not 3x for the split)
+            _launch_conv(p, xp, w_f, spec, impl=_IMPL, alg_flops=2.0 * B * frames * n_fft * 2 * (n_fft // 2 + 1))
             specs.append(spec)
         out = zeros_f32(3, x.device)
         L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.DT_F32, B * frames, nb, M, out.data_ptr(),
@@ -1187,7 +1200,7 @@ class StftSums(torch.autograd.Function):
         p = _new_params()
         _fill(p, B=B, Lin=frames, Cin=M, M=hop, Lout=rows, LoutTot=rows, J=J, off0=-(J - 1), out_f32=1 if split else 0)
         dxp = torch.empty((B, rows, hop), device=sx.device, dtype=torch.float32)
-        _launch_conv(p, dsx, w_d, dxp, impl=_IMPL)
+        _launch_conv(p, dsx, w_d, dxp, impl=_IMPL, alg_flops=2.0 * B * frames * n_fft * 2 * (n_fft // 2 + 1))
         dx = torch.empty((B, S), device=sx.device, dtype=torch.float32)
         L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.DT_F32, L.DT_F32, B, S, n_fft, hop, rows, 0, L.stream()),
                 "ga_stft_unpad_bwd")
