@@ -116,8 +116,22 @@ def pmc_traffic(kernel_name):
         return {}
     if not k:
         return {}
-    return {"traffic": round(k["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    out = {"traffic": round(k["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
+           "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    # MFMA utilisation of the same kernels from the newest committed counter pass (scratch/pmc_mfma.py:
+    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs))
+    mf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
+    if mf:
+        try:
+            with open(mf[-1]) as f:
+                kk = json.load(f)["kernels"]
+            if kernel_name in kk:
+                out["mfma_busy_frac"] = round(kk[kernel_name]["mfma_busy_frac"], 4)
+                out["mfma_busy_frac_wgrad_gemm_kernel"] = round(kk.get("wgrad_gemm_kernel", {}).get("mfma_busy_frac", float("nan")), 4)
+                out["mfma_busy_source"] = "profiles/" + os.path.basename(mf[-1])
+        except (OSError, ValueError, KeyError):
+            pass
+    return out
 
 
 def main():
@@ -130,6 +144,8 @@ def main():
     ap.add_argument("--no-batch12", action="store_true", help="skip the second measurement at the reference's default batch of 12")
     ap.add_argument("--frames", type=int, default=375, help="latent frames T (5 s x 75 Hz); S = 320*T samples")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--stft-stress", action="store_true", help="BASELINE config 5: the six MR-STFT resolutions (256 ... 8192) of SURVEY.md "
+                    "8(d); use with --frames 2250 (30 s clips, S = 720000) and a batch sized for the 288 GB of HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
@@ -170,6 +186,9 @@ def main():
     G, D, codec = make_models(args.precision, device, seed=328)
     scfg = CodecStageTrainConfig(stage_name="stage2", epochs=1, d_step_period=1, r1_gamma=0.0, g_grad_clip_norm=5.0,
                                  d_grad_clip_norm=5.0, weights=CodecTrainWeights(content=0.0, style=0.0))
+    if args.stft_stress:
+        scfg.wave_mrstft_resolutions = ((256, 64, 256), (512, 128, 512), (1024, 256, 1024), (2048, 512, 2048),
+                                        (4096, 1024, 4096), (8192, 2048, 8192))
     opt_g = FusedAdamW(G.parameters(), lr=scfg.lr_g, betas=scfg.betas)
     opt_d = FusedAdamW(D.parameters(), lr=scfg.lr_d, betas=scfg.betas)
     if dp is not None:
@@ -270,7 +289,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "lab3 codec GAN full-size codec shape (T=%d latent frames, S=%d samples), G 256ch x10 "
                                    "blocks, 3-scale D, frozen SEANet decoder; d_step_period=1, no R1, losses adv+FM+latent+"
-                                   "continuity+MR-STFT, clip 5 + AdamW" % (args.frames, args.frames * 320),
+                                   "continuity+MR-STFT%s, clip 5 + AdamW" % (args.frames, args.frames * 320,
+                                                                             " (six resolutions 256..8192)" if args.stft_stress else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "random_init_weights": True},
             "roofline": roofline,

@@ -111,3 +111,43 @@ def test_full_size_iteration_is_finite_and_moves_every_parameter(world):
     assert float(out["g_grad_norm"]) > 0 and float(out["d_grad_norm"]) > 0
     after = list(G.parameters()) + list(D.parameters())
     assert all(not torch.equal(a, b) for a, b in zip(after, before))
+
+
+# ---- BASELINE config 5: long clips (30 s: T = 2250 latent frames, S = 720000 samples) with six MR-STFT resolutions ------------
+STRESS_RES = ((256, 64, 256), (512, 128, 512), (1024, 256, 1024), (2048, 512, 2048), (4096, 1024, 4096), (8192, 2048, 8192))
+
+
+def test_long_clip_iteration_with_six_stft_resolutions():
+    """Decoder (2251-step LSTM), D and the six-resolution MR-STFT (n_fft up to 8192 at full length) forward and backward at
+    T = 2250, B = 2: finite losses, every parameter moves, the waveform has the right length, the MR-STFT of a signal with
+    itself vanishes at this size too, and batch items stay independent."""
+    G, D, codec = bench.make_models("bf16", DEV, seed=5)
+    Bl, Tl = 2, 2250
+    batch = bench.make_batch(Bl, Tl, DEV, torch.Generator().manual_seed(6))
+    scfg = T.CodecStageTrainConfig(stage_name="stage2", epochs=1, d_step_period=1, g_grad_clip_norm=5.0, d_grad_clip_norm=5.0,
+                                   wave_mrstft_resolutions=STRESS_RES, weights=CodecTrainWeights(content=0.0, style=0.0))
+    with torch.no_grad():
+        x = codec.decode_embeddings(batch[0])
+        assert x.shape == (Bl, 1, Tl * 320) and torch.isfinite(x).all()
+        x0 = codec.decode_embeddings(batch[0][:1])
+        assert rel(x[:1], x0) <= 1e-6
+    xp = x.clone().requires_grad_(True)
+    st = T._waveform_mrstft_loss(wav_pred=xp, wav_true=x, resolutions=STRESS_RES, precision="bf16")
+    assert abs(float(st)) <= 1e-6
+    st.backward()
+    assert float(xp.grad.abs().max()) <= 1e-6
+    y = torch.roll(x, 977, dims=2)
+    st2 = T._waveform_mrstft_loss(wav_pred=x, wav_true=y, resolutions=STRESS_RES, precision="bf16")
+    st3 = T._waveform_mrstft_loss(wav_pred=x, wav_true=y, resolutions=STRESS_RES, precision="fp32")
+    assert float(st2) > 0 and float(st2) == pytest.approx(float(st3), rel=2e-4)  # bf16 hi/lo split GEMM vs the exact fp32 DFT
+    opt_g = FusedAdamW(G.parameters(), lr=scfg.lr_g, betas=scfg.betas)
+    opt_d = FusedAdamW(D.parameters(), lr=scfg.lr_d, betas=scfg.betas)
+    before = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    out = T.codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, *batch, global_step=1)
+    vals = {k: float(v) for k, v in out.items() if v.dim() == 0}
+    assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
+    assert vals["loss_mrstft"] > 0 and vals["loss_fm"] > 0
+    assert out["x_hat"].shape == (Bl, 1, Tl * 320)
+    assert all(not torch.equal(a, b) for a, b in zip(list(G.parameters()) + list(D.parameters()), before))
+    from gan_amd import ops
+    assert not ops.lstm_persist_error()
