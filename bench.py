@@ -298,6 +298,7 @@ def main():
                                                     "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                                  for k, v in sorted(kernels.items())},
             "loss_g_last": round(loss_g, 5),
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
         }
         if batch12 is not None:
             line["batch12"] = batch12

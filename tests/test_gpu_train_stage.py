@@ -183,3 +183,23 @@ def test_lab1_adapter_shapes_and_gradient():
     mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
     want = (mel(1000.0) - mel(20.0)) / (mel(11025.0) - mel(20.0)) * 97 - 1
     assert abs(int(mt.argmax()) - want) <= 1.0
+
+
+def test_lab1_adapter_matches_the_cpu_oracle():
+    """gan_amd.lab1_adapter.Lab1WaveAdapter (fp32 on the GPU) against oracle/lab1_oracle.wave_to_logmel (float64 numpy, written
+    independently): both restate torchaudio's resample -> MelSpectrogram -> AmplitudeToDB (parity with torchaudio itself is
+    unpinned: it is not importable in the build image).  Bound: 2e-3 dB, where the dB value is above the batch floor."""
+    from gan_amd.lab1_adapter import Lab1WaveAdapter
+    from oracle import lab1_oracle as LO
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    t = torch.arange(120000) / 24000.0
+    wav = (0.05 * torch.randn(3, 1, 120000) + 0.3 * torch.sin(2 * torch.pi * (200.0 + 800.0 * torch.arange(3)[:, None, None]) * t))
+    got = Lab1WaveAdapter(24000, 22050, 256, dev)(wav.to(dev)).cpu().double().numpy()
+    want = LO.wave_to_logmel(wav.numpy(), 24000, 22050, 256)
+    assert got.shape == want.shape == (3, 96, 256)
+    assert np.abs(got - want).max() <= 2e-3
+    short = 0.1 * torch.randn(2, 1, 24000)
+    got = Lab1WaveAdapter(24000, 22050, 256, dev)(short.to(dev)).cpu().double().numpy()
+    want = LO.wave_to_logmel(short.numpy(), 24000, 22050, 256)
+    assert np.abs(got - want).max() <= 2e-3
