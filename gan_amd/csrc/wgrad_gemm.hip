@@ -49,10 +49,14 @@ static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0
 #define WGG_RK 64    // reduction rows per step
 #define WGG_TILE (WGG_RK * 256)  // bytes of one operand tile
 
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
+// NBUF = 2: next step's loads in flight behind the current multiply (64 KiB of LDS, two workgroups per CU).
+// NBUF = 1: one buffer, 32 KiB, 128 registers: four workgroups per CU hide each other's load round trips (the form that won for
+//           the forward kernel on grids several workgroups per CU deep).
+template <int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* const Al = smem;                 // [2][64][256 B]  G rows
-    char* const Bl = smem + 2 * WGG_TILE;  // [2][64][256 B]  gathered X rows
+    char* const Al = smem;                    // [NBUF][64][256 B]  G rows
+    char* const Bl = smem + NBUF * WGG_TILE;  // [NBUF][64][256 B]  gathered X rows
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -134,12 +138,16 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradParams p, int ktil
     }
     const bool wave_active = (mbase + wme * 64) < p.M && (kbase + wn * 64) < Kcols;
 
-    if (s_begin < s_end) issue(0);
+    if (NBUF == 2 && s_begin < s_end) issue(0);
     for (int st = s_begin; st < s_end; ++st) {
-        const int buf = (st - s_begin) & 1;
+        const int buf = NBUF == 2 ? (st - s_begin) & 1 : 0;
+        if (NBUF == 1) {
+            if (st > s_begin) __syncthreads();  // everyone is done reading the single buffer
+            issue(0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (st + 1 < s_end) issue(buf ^ 1);
+        if (NBUF == 2 && st + 1 < s_end) issue(buf ^ 1);
         if (wave_active) {
             const char* Ab = Al + buf * WGG_TILE;
             const char* Bb = Bl + buf * WGG_TILE;
@@ -214,7 +222,7 @@ static long wgg_target_blocks() {
     static long v = -1;
     if (v < 0) {
         const char* e = getenv("GA_WGRAD_TARGET");
-        v = e ? atol(e) : 768;
+        v = e ? atol(e) : 2048;  // four single-buffer workgroups are resident per CU; swept 768 / 1024 / 1536 / 2560 at B = 24 and 128
         if (v < 1) v = 1;
     }
     return v;
@@ -227,9 +235,18 @@ static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, l
     ktiles = (Ktot + 127) / 128;
     base = (long)mtiles * ktiles;
     nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
-    splits = (wgg_target_blocks() + base - 1) / base;  // workgroups aimed for (two are resident per CU: 64 KB of LDS each)
-    const long max_splits = (nsteps + 7) / 8;       // at least 8 steps (512 rows) per split
-    if (splits > max_splits) splits = max_splits;
+    splits = (wgg_target_blocks() + base - 1) / base;  // workgroups aimed for
+    // at least 48 steps (3072 rows) per split: shorter slices are dominated by their prologue and the fp32 atomics of their
+    // 64 KiB tile (swept at B = 24) - unless the grid would then leave CUs idle (the generator's few-tile layers), where
+    // slices go down to 8 steps to reach about two workgroups per CU
+    const long cap48 = (nsteps + 47) / 48, cap8 = (nsteps + 7) / 8;
+    if (splits > cap48) splits = cap48;
+    if (splits < 1) splits = 1;
+    if (base * splits < 512) {
+        long want = (512 + base - 1) / base;
+        if (want > cap8) want = cap8;
+        if (want > splits) splits = want;
+    }
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     sps = (int)((nsteps + splits - 1) / splits);
@@ -257,14 +274,23 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
     int sps, ktiles;
     wgg_plan(p, base, splits, sps, nsteps, ktiles);
     if (p.ws && (((uintptr_t)p.ws & 15) || ((size_t)p.M * Ktot) % 4)) return GA_ERR_ALIGN;
-    const size_t lds = 4 * WGG_TILE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GA_ERR_LAUNCH;
-        attr_set = true;
+    static int nbuf = -1;
+    if (nbuf < 0) {
+        const char* e = getenv("GA_WGRAD_NBUF");
+        nbuf = (e && e[0] == '2') ? 2 : 1;  // single buffer by default: 20-40 % faster on every D layer (B = 24 and 128)
     }
-    wgrad_gemm_kernel<<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    if (nbuf == 1) {
+        wgrad_gemm_kernel<1><<<dim3((unsigned)base, (unsigned)splits), 256, 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    } else {
+        const size_t lds = 4 * WGG_TILE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return GA_ERR_LAUNCH;
+            attr_set = true;
+        }
+        wgrad_gemm_kernel<2><<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    }
     GA_CHECK_LAUNCH();
     if (p.ws) {
         const long n4 = (long)p.M * Ktot / 4;

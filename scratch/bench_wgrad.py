@@ -3,10 +3,11 @@ sys.path.insert(0, ".")
 from gan_amd import _lib as L, ops
 from gan_amd.ops import ConvGeom
 S = 120000
+BB = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 cases = []
 for sc, s in enumerate((S, S // 2, S // 4)):
-    cases += [(f"D{sc}.b1", ConvGeom("conv", 32, 64, 41, 4, 20, 1), s, 24), (f"D{sc}.b2", ConvGeom("conv", 64, 128, 41, 4, 20, 1), s // 4, 24),
-              (f"D{sc}.b3", ConvGeom("conv", 128, 256, 41, 4, 20, 1), s // 16, 24), (f"D{sc}.b4", ConvGeom("conv", 256, 512, 41, 4, 20, 1), s // 64, 24)]
+    cases += [(f"D{sc}.b1", ConvGeom("conv", 32, 64, 41, 4, 20, 1), s, BB), (f"D{sc}.b2", ConvGeom("conv", 64, 128, 41, 4, 20, 1), s // 4, BB),
+              (f"D{sc}.b3", ConvGeom("conv", 128, 256, 41, 4, 20, 1), s // 16, BB), (f"D{sc}.b4", ConvGeom("conv", 256, 512, 41, 4, 20, 1), s // 64, BB)]
 cases += [("G.in", ConvGeom("conv", 128, 256, 3, 1, 1, 1), 375, 12), ("G.blk", ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 12)]
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
