@@ -27,7 +27,7 @@ sys.path.insert(0, str(REPO))
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_NAMES = {0: "conv_direct_kernel", 1: "conv_fewout_kernel", 2: "conv_cin1_kernel",
                 3: "conv_mfma_kernel<1,4,32>", 4: "conv_mfma_kernel<2,2,64>", 5: "conv_fewout_rows_kernel",
-                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>", 10: "conv_stream_kernel", 11: "conv_pp_kernel"}
+                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>", 10: "conv_stream_kernel", 11: "conv_pp_kernel", 12: "conv_win_kernel"}
 
 
 def make_models(precision: str, device, seed: int):
@@ -149,8 +149,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
-    ap.add_argument("--prefetch", action="store_true", help="decode the next batch's frozen latents one iteration ahead on a side "
-                    "stream (gan_amd/prefetch.py; measured slower on MI355X: the two launch-bound chains do not overlap)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
     ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass instead of after it")
@@ -195,9 +193,6 @@ def main():
         dp.broadcast_params(opt_g, opt_d)
     gen = torch.Generator().manual_seed(328 + rank)
 
-    # optional (train_codec_stage(prefetch=True)): the next batch's frozen latents decoded on a side stream
-    from gan_amd.prefetch import FrozenDecodePrefetcher
-    prefetcher = FrozenDecodePrefetcher(codec) if args.prefetch else None
     state = {"batches": None, "i": 0}
 
     def step(_i=None):
@@ -205,9 +200,7 @@ def main():
         state["i"] += 1
         batches = state["batches"]
         b = batches[i % len(batches)]
-        nb = batches[(i + 1) % len(batches)]
-        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp,
-                                     prefetcher=prefetcher, next_frozen=[nb[0], nb[4], nb[5]] if prefetcher else None)
+        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
 
     def barrier():
         if dp is not None:
@@ -267,7 +260,7 @@ def main():
             b_, cin_, m_, j_, lout_, _nph, istr_ = shape[:7]
             # algorithmic bytes of one launch: the input window once, the packed weights once, the output once
             k["bytes"] += esz * (b_ * lout_ * max(1, istr_) * cin_ + m_ * j_ * cin_ + b_ * lout_ * m_)
-        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9, 11)), key=lambda k: kernels[k]["ms"], default=None)
+        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9, 11, 12)), key=lambda k: kernels[k]["ms"], default=None)
         if dom is not None:
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12

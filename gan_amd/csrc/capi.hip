@@ -10,6 +10,9 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_finish(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_suggest_ksplit(const ConvParams& p);
 int ga_conv_splitk_static_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_win_supported(const ConvParams& p);
+int ga_conv_win_wanted(const ConvParams& p);
+int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_pp_supported(const ConvParams& p);
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
@@ -37,6 +40,7 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     const bool can_mfma = dtype == GA_DTYPE_BF16 && ga_conv_mfma_supported(p);
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
     if (impl == GA_IMPL_MFMA_PP) return (dtype == GA_DTYPE_BF16 && ga_conv_pp_supported(p)) ? ga_conv_pp_impl(p, s) : GA_ERR_ARG;
+    if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? ga_conv_win_impl(p, s) : GA_ERR_ARG;
     // thin bf16 layers (M <= 64, K <= 192): the register-streaming MFMA kernel, which is also the one that fuses ELU(x)
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_stream_impl(p, s);
@@ -85,13 +89,16 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
     const bool big = (long)p.Lout * p.B >= 64 || p.out_f32;
     if (impl == GA_IMPL_MFMA_PP) return (dtype == GA_DTYPE_BF16 && ga_conv_pp_supported(p)) ? GA_KERNEL_GEMM_PP : -1;
+    if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? GA_KERNEL_CONV_WIN : -1;
     if (p.res_mode != GA_RES_ADD) {  // ga_conv: gathered-GEMM kernel or nothing
         if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
+        if (ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
         if (ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
         return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
     }
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return GA_KERNEL_STREAM;
+    if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
     const bool mfma = ((impl == GA_IMPL_MFMA || impl == GA_IMPL_MFMA_WINDOW) && can_mfma) || (impl == GA_IMPL_AUTO && can_mfma && big);

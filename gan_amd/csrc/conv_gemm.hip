@@ -58,7 +58,7 @@ template <int MI, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && MI == 2) ? GA_GEMM_NBUF1_WAVES : 1)) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
     constexpr int WMR = MI * 32;               // rows (m) per wave
     constexpr int BM = WM * WMR, BN = WN * 64;
-    constexpr int NT = WM * WN * 64;           // threads: WM x WN waves (4, or 8 for the 256x128 tile)
+    constexpr int NT = WM * WN * 64;           // threads: WM x WN waves
     constexpr int RPI = NT / 8;                // tile rows one load instruction of the workgroup covers
     constexpr int NA = (BM * 8 + NT - 1) / NT; // 16-byte pieces per thread per K-step, A (weights)
     constexpr int NB = BN * 8 / NT;            // same, B (gathered activations)
@@ -523,25 +523,6 @@ static int gemm_half_max_blocks() {
     return v;
 }
 
-// GA_GEMM_WIDE: 0 = never use the 256x128 eight-wave tile, 2 / 3 = use it with that many LDS buffers (tuning aid)
-static int gemm_wide_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GA_GEMM_WIDE");
-        v = e ? atoi(e) : 0;
-        if (v != 2 && v != 3) v = 0;
-    }
-    return v;
-}
-static int gemm_wide_min_blocks() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GA_GEMM_WIDE_MIN");
-        v = e ? atoi(e) : 600;
-    }
-    return v;
-}
-
 // grids of at least this many 128x128 workgroups take the single-buffer kernel (four workgroups per CU); GA_GEMM_NBUF1_MIN
 // overrides (tuning aid)
 static int gemm_single_min_blocks() {
@@ -595,10 +576,13 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
 
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_win_wanted(const ConvParams& p);
+int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
+    if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
     if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
     // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
     // wants the second buffer
@@ -614,11 +598,6 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
         if (2 * blocks <= gemm_deep_max_blocks() && ksteps >= 6) return launch_gemm<1, 2, 2, 4>(p, s);
         return launch_gemm<1, 2, 2, 2>(p, s);
     }
-    // many tiles and >= 256 output channels: 256x128 tiles on eight waves.  The 128x128 kernel moves 32 KB into LDS per
-    // 2.1 MFLOP (64 FLOP/B) and runs at 60-75 % of the ~18 TB/s the chip's L2s deliver to direct-to-LDS gathers; the wide
-    // tile needs 48 KB per 4.2 MFLOP (85 FLOP/B)
-    if (!gemm_nbuf_override() && gemm_wide_mode() && p.M >= 256 && p.M % 256 == 0 && blocks >= gemm_wide_min_blocks())
-        return gemm_wide_mode() == 3 ? launch_gemm<2, 4, 2, 3>(p, s) : launch_gemm<2, 4, 2, 2>(p, s);
     int nbuf = gemm_nbuf_override();
     if (!nbuf) nbuf = blocks >= gemm_single_min_blocks() ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
     return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);

@@ -255,8 +255,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
                           discriminator: MultiScaleWaveDiscriminator, codec, opt_g: FusedAdamW, opt_d: FusedAdamW,
                           q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
                           q_real_tgt: Optional[torch.Tensor], q_real_tgt_g: torch.Tensor, global_step: int,
-                          noise2: Optional[torch.Tensor] = None, dp=None, prefetcher=None,
-                          next_frozen: Optional[List[torch.Tensor]] = None, style_judge=None,
+                          noise2: Optional[torch.Tensor] = None, dp=None, style_judge=None,
                           tgt_genre_idx: Optional[torch.Tensor] = None,
                           src_genre_idx: Optional[torch.Tensor] = None, lab1_encoder=None, lab1_adapter=None,
                           lab1_probe=None, mert_probe=None, zs_src: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -264,9 +263,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     style_judge (+ tgt_genre_idx / src_genre_idx, device int64 [B]): the frozen CodecStyleJudge of style_loss_mode
     "codec_judge_ce" (:480-494).  lab1_encoder + lab1_adapter (+ zs_src, lab1_probe, mert_probe): the content term and the
     Lab1 / probe style modes (:472-475,495-550), the caller's frozen modules run as ordinary PyTorch on the log-mel of x_hat.
-    With neither a judge nor a Lab1 encoder the content and style terms stay at zero (the north-star loss subset).
-    prefetcher / next_frozen: see gan_amd/prefetch.py - the frozen latents of the NEXT iteration ([q_src, q_real_tgt (if
-    that iteration takes a D step), q_real_tgt_g]) are decoded on a side stream while this iteration runs."""
+    With neither a judge nor a Lab1 encoder the content and style terms stay at zero (the north-star loss subset)."""
     device = q_src.device
     out: Dict[str, torch.Tensor] = {}
     q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
@@ -277,12 +274,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     # third of the (launch-bound) LSTM steps.
     B0 = int(q_src.shape[0])
     frozen_list = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
-    frozen_out = prefetcher.take(frozen_list) if prefetcher is not None else None
-    if prefetcher is not None and next_frozen:
-        prefetcher.launch(next_frozen)
-    if frozen_out is not None:
-        x_hat = codec.decode_embeddings(q_hat)
-    elif hasattr(codec, "decode_embeddings_mixed"):
+    if hasattr(codec, "decode_embeddings_mixed"):
         x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, torch.cat(frozen_list, dim=0))
     else:
         x_hat = codec.decode_embeddings(q_hat)
@@ -437,7 +429,7 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
                       discriminator: MultiScaleWaveDiscriminator, codec, lab1_encoder, style_judge, train_loader, n_genres: int,
                       style_centroid_bank: torch.Tensor, style_exemplar_bank: Optional[Dict[int, torch.Tensor]],
                       q_exemplar_bank: Dict[int, torch.Tensor], out_ckpt_dir: Path, device: torch.device, resume: bool = False,
-                      lab1_probe=None, mert_probe=None, dp=None, prefetch: bool = False) -> List[Dict]:
+                      lab1_probe=None, mert_probe=None, dp=None) -> List[Dict]:
     """reference :267-648.  Same arguments and the same 19-key history rows.  Losses are accumulated on the device and
     read back once per epoch (the reference syncs 12 scalars per iteration, :593-604)."""
     w = stage_cfg.weights
@@ -477,9 +469,6 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
 
     hist_rows: List[Dict] = []
     global_step = 0
-    from .prefetch import FrozenDecodePrefetcher
-    # off by default: on MI355X / ROCm 7.2 the side-stream chain was measured not to overlap with the main stream
-    prefetcher = FrozenDecodePrefetcher(codec) if (prefetch and device.type == "cuda") else None
     keys = ("loss_g", "loss_d", "loss_adv", "loss_fm", "loss_lat_l1", "loss_lat_cont", "loss_content", "loss_style",
             "loss_style_embed", "loss_style_push", "loss_delta_budget", "loss_mrstft", "loss_ms")
     for epoch in range(start_epoch + 1, int(stage_cfg.epochs) + 1):
@@ -490,10 +479,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
         acc = {k: torch.zeros((), device=device) for k in keys}
         d_steps_taken = d_steps_skipped = n_batches = 0
         def prepare(bi, batch, step):
-            """Everything one iteration draws or moves before its generator pass (the reference's :361-404,420,456), in the
-            reference's order of random draws.  Without `prefetch` it runs at the top of its own iteration, so a seed gives
-            the reference's sequence of CPU and device draws; with `prefetch` it runs one batch ahead (the next batch's
-            frozen latents go to the side-stream decode) and the draws of batch i+1 precede batch i's in-forward ones."""
+            """Everything one iteration draws or moves before its generator pass (the reference's :361-404), in the reference's
+            order of random draws: CPU generator for the exemplar rows, device generator for the shifted targets (when
+            target_balance is off), the exemplar noise and sample_noise - so a seed reproduces the reference's sequence."""
             q_src = batch["q_emb"].to(device, non_blocking=True).float()
             zc_src = F.normalize(batch["z_content"].to(device, non_blocking=True).float(), dim=-1)
             zs_src = F.normalize(batch["z_style"].to(device, non_blocking=True).float(), dim=-1)
@@ -525,51 +513,25 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             need_idx = use_judge or lab1_probe is not None
             tgt_dev = tgt_genre_idx.to(device, non_blocking=True) if need_idx else None
             src_dev = src_genre_idx.to(device, non_blocking=True) if need_idx else None
-            item = dict(q_src=q_src, zc_src=zc_src, zs_src=zs_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, step=step,
-                        tgt_genre_idx=tgt_dev, src_genre_idx=src_dev, tgt_host=tgt_genre_idx)
-            if prefetcher is not None:
-                draw_bank_rows(item)
-            return item
+            # q_real_tgt (D step, :420) then q_real_tgt_g (G step, :456): CPU-generator picks, in the reference's order (no other
+            # CPU draw separates them from their place in the reference)
+            q_real_tgt = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float() if take_d else None
+            q_real_tgt_g = _sample_bank_rows(q_exemplar_bank, tgt_genre_idx, device=device).float()
+            return dict(q_src=q_src, zc_src=zc_src, zs_src=zs_src, z_style_tgt=z_style_tgt, noise=noise, take_d=take_d, step=step,
+                        tgt_genre_idx=tgt_dev, src_genre_idx=src_dev, q_real_tgt=q_real_tgt, q_real_tgt_g=q_real_tgt_g)
 
-        def draw_bank_rows(item):
-            """q_real_tgt (D step, :420) then q_real_tgt_g (G step, :456): CPU-generator picks, in the reference's order."""
-            item["q_real_tgt"] = (_sample_bank_rows(q_exemplar_bank, item["tgt_host"], device=device).float()
-                                  if item["take_d"] else None)
-            item["q_real_tgt_g"] = _sample_bank_rows(q_exemplar_bank, item["tgt_host"], device=device).float()
-
-        def frozen_of(item):
-            return [item["q_src"]] + ([item["q_real_tgt"]] if item["take_d"] else []) + [item["q_real_tgt_g"]]
-
-        def batches():
-            for bi, batch in enumerate(train_loader):
-                if stage_cfg.max_batches_per_epoch is not None and bi >= int(stage_cfg.max_batches_per_epoch):
-                    return
-                yield bi, batch
-
-        it = batches()
-        nxt = next(it, None)
-        cur = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
-        while cur is not None:
+        for bi, batch in enumerate(train_loader):
+            if stage_cfg.max_batches_per_epoch is not None and bi >= int(stage_cfg.max_batches_per_epoch):
+                break
             global_step += 1
             n_batches += 1
-            nxt = next(it, None)
-            ahead = None
-            if prefetcher is not None:
-                ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
-            else:
-                # No device-side random draw separates these two host picks from their place in the reference (:420, :456), and
-                # the G forward's own draws (dropout, jitter) come after prepare()'s, as there.
-                draw_bank_rows(cur)
+            cur = prepare(bi, batch, global_step)
             take_d = cur["take_d"]
             res = codec_train_iteration(stage_cfg, generator, discriminator, codec, opt_g, opt_d, cur["q_src"], cur["zc_src"],
                                         cur["z_style_tgt"], cur["noise"], cur["q_real_tgt"], cur["q_real_tgt_g"], global_step,
-                                        dp=dp, prefetcher=prefetcher, next_frozen=frozen_of(ahead) if ahead is not None else None,
-                                        style_judge=style_judge, tgt_genre_idx=cur["tgt_genre_idx"],
+                                        dp=dp, style_judge=style_judge, tgt_genre_idx=cur["tgt_genre_idx"],
                                         src_genre_idx=cur["src_genre_idx"], lab1_encoder=lab1_encoder, lab1_adapter=lab1_adapter,
                                         lab1_probe=lab1_probe, mert_probe=mert_probe, zs_src=cur["zs_src"])
-            if prefetcher is None:
-                ahead = prepare(nxt[0], nxt[1], global_step + 1) if nxt is not None else None
-            cur = ahead
             if take_d:
                 d_steps_taken += 1
             else:
@@ -579,6 +541,9 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
                     acc[k] += res[k].reshape(())
         n = max(1, n_batches)
         host = {k: float(v) for k, v in acc.items()}  # one sync per epoch
+        if device.type == "cuda" and ops.lstm_persist_error(device):
+            raise RuntimeError("a persistent LSTM launch of the frozen decoder ran out of its bounded wait (lstm_persist.hip): its "
+                               "workgroups were not all resident; this epoch's results are invalid (set gan_amd.ops.LSTM_PERSIST = False)")
         row = {
             "stage": str(stage_cfg.stage_name), "epoch": int(epoch), "loss_g": host["loss_g"] / n,
             "loss_d": (host["loss_d"] / max(1, d_steps_taken)) if d_steps_taken > 0 else 0.0,

@@ -135,11 +135,11 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
-    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_PP):
+    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_PP, L.IMPL_MFMA_LDSWIN):
         p, bias = _fold_phases(p, x, bias)
     # few output tiles x deep K (D blocks 3-4): split K over workgroups, one fp32 partial-sum slab per slice
     ks = L.lib().ga_conv_suggest_ksplit(C.byref(p), L.dt(x), impl) if SPLIT_K else 1
-    if FORCE_KSPLIT is not None and L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl) in (7, 8, 9, 11):
+    if FORCE_KSPLIT is not None and L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl) in (7, 8, 9, 11, 12):
         ks = max(1, min(int(FORCE_KSPLIT), (p.J * p.Cin + 63) // 64))
     ws = None
     if ks > 1:
@@ -293,7 +293,7 @@ def fm_sign_fusable(g: ConvGeom, gy: Tensor, lin: int) -> bool:
     p.x = p.w = p.y = p.res = p.dact_src = p.res_coef_dev = 256  # alignment checks only: nothing is dereferenced
     if MERGE_PHASES:
         p, _ = _fold_phases(p, gy, None)
-    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(gy), _IMPL) in (7, 8, 9, 11)
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(gy), _IMPL) in (7, 8, 9, 11, 12)
 
 
 def conv_wgrad(g: ConvGeom, ga: Tensor, x: Tensor, want_bias: bool = False):

@@ -838,3 +838,35 @@ def test_lstm_skip_matches_torch_lstm(B, T, dtype, persist, monkeypatch):
     with torch.no_grad():  # inference path (no saved gates)
         close(ops.LstmSkip.apply(x.to(DEV, dtype), w), y_ref, tol, "lstm fwd nograd")
     assert not ops.lstm_persist_error()
+
+
+def test_lds_window_kernel_matches_gathered_and_direct_kernels():
+    """conv_win_kernel (input rows of a tile staged once in LDS, taps read from the window) on the two problem forms it takes:
+    D blocks.1 forward (Cin 32, stride 4, k 41, zero padding at both ends, ragged last tile, fewer than 64 output channels too)
+    and its phase-folded data gradient (Cin 64, stride 1, 11 taps, LeakyReLU mask in the epilogue).  Same bf16 operands and fp32
+    accumulation order per output as the gathered kernel, so the two agree to the last bit; the direct kernel bounds both."""
+    torch.manual_seed(33)
+    for g, Ln, B in ((ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 3), (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 1024, 2),
+                     (ConvGeom("conv", 32, 48, 41, 4, 20, 1), 2050, 2)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+        src = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+        outs = {}
+        for name, impl in (("window", L.IMPL_MFMA_LDSWIN), ("gather", L.IMPL_MFMA), ("direct", L.IMPL_DIRECT)):
+            ops.set_conv_impl(impl)
+            try:
+                fwd = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU).float().cpu()
+                dgr = None
+                if g.cout == 64:  # the folded data gradient has 4 * 32 = 128 output channels and Cin = 64
+                    dgr = ops.conv_dgrad(g, gy, wd, Ln, dact_mode=L.DACT_LRELU_FROM_OUT, dact_src=src).float().cpu()
+                outs[name] = (fwd, dgr)
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
+        assert torch.equal(outs["window"][0], outs["gather"][0]), g
+        close(outs["window"][0], outs["direct"][0], 1e-2, f"window fwd {g} L={Ln}")
+        if outs["window"][1] is not None:
+            assert torch.equal(outs["window"][1], outs["gather"][1]), g
+            close(outs["window"][1], outs["direct"][1], 1e-2, f"window dgrad {g} L={Ln}")

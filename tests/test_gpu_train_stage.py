@@ -27,8 +27,7 @@ def _loader(n, T, n_genres, bs, seed):
     return batches, q, zs, gi
 
 
-@pytest.mark.parametrize("prefetch", [False, True])
-def test_train_codec_stage_runs_checkpoints_and_resumes(tmp_path, prefetch):
+def test_train_codec_stage_runs_checkpoints_and_resumes(tmp_path):
     torch.manual_seed(328)
     dev = torch.device("cuda")
     n_genres, T = 3, 16
@@ -41,7 +40,7 @@ def test_train_codec_stage_runs_checkpoints_and_resumes(tmp_path, prefetch):
     kw = dict(lab1_encoder=None, style_judge=None, train_loader=batches, n_genres=n_genres,
               style_centroid_bank=build_style_centroid_bank(zs, gi, n_genres),
               style_exemplar_bank=build_style_exemplar_bank(zs, gi, n_genres),
-              q_exemplar_bank=build_q_exemplar_bank(q, gi, n_genres), out_ckpt_dir=tmp_path, device=dev, prefetch=prefetch)
+              q_exemplar_bank=build_q_exemplar_bank(q, gi, n_genres), out_ckpt_dir=tmp_path, device=dev)
     rows = train_codec_stage(cfg, G, D, codec, **kw)
     assert len(rows) == 2 and all(set(r) == ROW_KEYS for r in rows)
     assert all(np.isfinite(r["loss_g"]) and np.isfinite(r["loss_d"]) for r in rows)
