@@ -21,6 +21,7 @@
 // error word and runs through without waiting (results are then wrong, the error word says so, nothing hangs).
 // All 64*groups workgroups must be resident at once: the host launches at most one workgroup per CU.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -56,7 +57,7 @@ __device__ __forceinline__ bool lp_wait(unsigned* cnt, unsigned* err, unsigned t
 }
 
 template <int NBT>
-__global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(ga_lstm_params p, LstmPersistWs ws, int b_first) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_persist_kernel(ga_lstm_params p, LstmPersistWs ws, int b_first, int affine) {
     constexpr int H = LP_H, NB = NBT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const W1s = smem;                                   // [32][LP_W1_STRIDE]
@@ -65,7 +66,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(ga_lstm_params p,
     __bf16* const hst = (__bf16*)(red + 4 * 3 * NBT * 64);    // [2 layers][NB][8]
     __shared__ int dead_s;
 
-    const int j = blockIdx.x % LP_WG_PER_GROUP, g = blockIdx.x / LP_WG_PER_GROUP;
+    // workgroup -> (group g, unit slice j).  affine > 0 (= the number of groups, grid of 256): the 64 workgroups of a group are
+    // the ones the dispatcher deals to TWO of the eight XCDs (blocks b and b + 8 share an XCD), so a group's exchange lines
+    // are fetched into two L2s instead of eight; workgroups of unused XCD pairs leave at once.  Placement only changes speed.
+    int j, g;
+    if (affine > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = xcd >> 1;
+        j = (xcd & 1) * 32 + slot;
+        if (g >= affine) return;
+    } else {
+        j = blockIdx.x % LP_WG_PER_GROUP;
+        g = blockIdx.x / LP_WG_PER_GROUP;
+    }
     const int b0 = b_first + g * NB;          // first batch item of this group
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(ga_lstm_params p,
                     hb1[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, 16);  // sc1
                     hb2[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off + LP_WG_PER_GROUP * NB * 16, 0, 16);
                 }
+            __builtin_amdgcn_sched_barrier(0);  // every exchange load of the step is in flight before the first MFMA waits on one
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -266,6 +280,15 @@ extern "C" size_t ga_lstm_persist_workspace_bytes(int B) {
     return LP_WS_HEADER + (size_t)4 * (2 * 2 * 4 * LP_WG_PER_GROUP * 64 * 16);
 }
 
+static int lp_affine() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GA_LSTM_AFFINE");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 static int lp_cu_count() {
     static int cus = -1;
     if (cus < 0) {
@@ -293,13 +316,14 @@ int ga_lstm_fwd_persist(const ga_lstm_params& p, hipStream_t s) {
         ws.cnt = (unsigned*)p.ws + 32;
         ws.hx = (char*)p.ws + LP_WS_HEADER;
         const size_t lds = lp_lds_bytes(nbt);
-        const dim3 grid(groups * LP_WG_PER_GROUP);
+        const int affine = (lp_affine() && cus >= 256) ? groups : 0;
+        const dim3 grid(affine ? 256 : groups * LP_WG_PER_GROUP);
 #define LP_LAUNCH(N)                                                                                                     \
     do {                                                                                                                 \
         if (hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                 (int)lds) != hipSuccess)                                                                 \
             return GA_ERR_LAUNCH;                                                                                        \
-        lstm_fwd_persist_kernel<N><<<grid, 256, lds, s>>>(p, ws, b_first);                                               \
+        lstm_fwd_persist_kernel<N><<<grid, 256, lds, s>>>(p, ws, b_first, affine);                                               \
     } while (0)
         switch (nbt) {
             case 1: LP_LAUNCH(1); break;
@@ -326,16 +350,28 @@ int ga_lstm_fwd_persist(const ga_lstm_params& p, hipStream_t s) {
 #define LP_WT_STRIDE 4112  // bytes per LDS row (2048 bf16 + 16)
 
 template <int NBT>
-__global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(ga_lstm_bwd_params p, LstmPersistWs ws, int b_first) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_persist_kernel(ga_lstm_bwd_params p, LstmPersistWs ws, int b_first, int affine) {
     constexpr int H = LP_H, NB = NBT * 16, NPC = 4 * LP_WG_PER_GROUP;  // pieces per (parity, layer)
-    constexpr int CH = NBT <= 2 ? 16 : 8;                              // K-steps whose operands are requested together
+    constexpr int CH = NBT == 1 ? 16 : NBT == 2 ? 8 : 4;                // K-steps whose operands are requested together (<= 128 registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Ws = smem;                                             // [24][LP_WT_STRIDE]: W_hh_l1^T | W_ih_l1^T | W_hh_l0^T rows
     float* const red = (float*)(Ws + 24 * LP_WT_STRIDE);               // [2 tiles X,Y][4 waves][NBT][64 lanes][4]
     __bf16* const dgst = (__bf16*)(red + 2 * 4 * NBT * 64 * 4);        // [2 layers][4 gates][NB][8]
     __shared__ int dead_s;
 
-    const int j = blockIdx.x % LP_WG_PER_GROUP, g = blockIdx.x / LP_WG_PER_GROUP;
+    // workgroup -> (group g, unit slice j).  affine > 0 (= the number of groups, grid of 256): the 64 workgroups of a group are
+    // the ones the dispatcher deals to TWO of the eight XCDs (blocks b and b + 8 share an XCD), so a group's exchange lines
+    // are fetched into two L2s instead of eight; workgroups of unused XCD pairs leave at once.  Placement only changes speed.
+    int j, g;
+    if (affine > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = xcd >> 1;
+        j = (xcd & 1) * 32 + slot;
+        if (g >= affine) return;
+    } else {
+        j = blockIdx.x % LP_WG_PER_GROUP;
+        g = blockIdx.x / LP_WG_PER_GROUP;
+    }
     const int b0 = b_first + g * NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
@@ -506,13 +542,14 @@ int ga_lstm_bwd_persist(const ga_lstm_bwd_params& p, hipStream_t s) {
         ws.cnt = (unsigned*)p.ws + 32;
         ws.hx = (char*)p.ws + LP_WS_HEADER;
         const size_t lds = lp_bwd_lds_bytes(nbt);
-        const dim3 grid(groups * LP_WG_PER_GROUP);
+        const int affine = (lp_affine() && cus >= 256) ? groups : 0;
+        const dim3 grid(affine ? 256 : groups * LP_WG_PER_GROUP);
 #define LP_LAUNCH(N)                                                                                                     \
     do {                                                                                                                 \
         if (hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                 (int)lds) != hipSuccess)                                                                 \
             return GA_ERR_LAUNCH;                                                                                        \
-        lstm_bwd_persist_kernel<N><<<grid, 256, lds, s>>>(p, ws, b_first);                                               \
+        lstm_bwd_persist_kernel<N><<<grid, 256, lds, s>>>(p, ws, b_first, affine);                                               \
     } while (0)
         switch (nbt) {
             case 1: LP_LAUNCH(1); break;
