@@ -365,6 +365,16 @@ def register_param_range(lo: int, hi: int) -> list:
     return holder
 
 
+def unregister_param_range(lo: int, hi: int) -> None:
+    """The optimizer that owned [lo, hi) is gone (FusedAdamW registers this as its finalizer): drop its epoch and every packed
+    weight cached for parameters in that range, so neither outlives the buffer (a later tensor at a recycled address can then
+    never meet a stale pack, and the bf16 packs of a finished stage do not stay resident)."""
+    global _EPOCH_RANGES
+    _EPOCH_RANGES = [r for r in _EPOCH_RANGES if not (r[0] == lo and r[1] == hi)]
+    for k in [k for k in _PACK_CACHE if lo <= k[0] < hi]:
+        del _PACK_CACHE[k]
+
+
 def _epoch_holder(ptr: int):
     for lo, hi, h in _EPOCH_RANGES:
         if lo <= ptr < hi:

@@ -46,7 +46,10 @@ class FusedAdamW:
                 p.data = view
         self.grad_views = [self.flat_g[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         from . import ops
-        self._epoch = ops.register_param_range(self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * n)  # packed-weight cache
+        lo, hi = self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * n
+        self._epoch = ops.register_param_range(lo, hi)  # packed-weight cache
+        import weakref
+        weakref.finalize(self, ops.unregister_param_range, lo, hi)  # packs and epoch go when this optimizer does
         self.last_grad_norm: Optional[torch.Tensor] = None
         self.grad_scale = 1.0  # 1/world_size when flat_g holds a SUM over ranks
 

@@ -8,7 +8,7 @@ out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt -o p -- python3 bench.py $args > $out/kt.log 2>&1 || { echo "kernel trace failed"; tail -5 $out/kt.log; exit 1; }
 db=$(find $out/kt -name "*.db" | head -1)
-python scratch/prof_summary.py $db gpurun_out/${tag}_kernel_stats.csv 8 | tee gpurun_out/${tag}_kernel_summary.txt
+python scratch/prof_summary.py $db gpurun_out/${tag}_kernel_stats.csv 9 | tee gpurun_out/${tag}_kernel_summary.txt
 tail -1 $out/kt.log > gpurun_out/${tag}_bench_line_under_trace.json
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   name=${pass%%:*}; ctrs=${pass#*:}

@@ -870,3 +870,25 @@ def test_lds_window_kernel_matches_gathered_and_direct_kernels():
         if outs["window"][1] is not None:
             assert torch.equal(outs["window"][1], outs["gather"][1]), g
             close(outs["window"][1], outs["direct"][1], 1e-2, f"window dgrad {g} L={Ln}")
+
+
+def test_pack_cache_is_released_with_its_optimizer():
+    """Packed weights are cached per optimizer epoch; when the FusedAdamW that owns the parameter buffer is dropped (one per
+    train_codec_stage call), its packs and its epoch range go with it instead of staying resident for the life of the process."""
+    import gc
+    from gan_amd.lab3_codec_models import MultiScaleWaveDiscriminator
+    from gan_amd.optim import FusedAdamW
+    D = MultiScaleWaveDiscriminator(1, precision="bf16").to(DEV)
+    opt = FusedAdamW(D.parameters(), lr=1e-3)
+    lo, hi = opt.flat_p.data_ptr(), opt.flat_p.data_ptr() + 4 * opt.numel
+    D(torch.randn(2, 1, 2048, device=DEV))
+    assert any(lo <= k[0] < hi for k in ops._PACK_CACHE) and any(r[0] == lo for r in ops._EPOCH_RANGES)
+    del opt
+    gc.collect()
+    assert not any(lo <= k[0] < hi for k in ops._PACK_CACHE) and not any(r[0] == lo for r in ops._EPOCH_RANGES)
+    y1 = D(torch.ones(2, 1, 2048, device=DEV))[0][0]  # still works without an optimizer (packs rebuilt per call, not cached)
+    with torch.no_grad():
+        for p in D.parameters():
+            p.mul_(0.5)
+    y2 = D(torch.ones(2, 1, 2048, device=DEV))[0][0]
+    assert not torch.equal(y1, y2)
