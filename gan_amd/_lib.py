@@ -116,6 +116,8 @@ _SIGNATURES = {
     "ga_stft_combine": [_P, _P, _I, _P, _P, _P, _P],
     "ga_stft_loss_fwd": [_P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_stft_loss_bwd": [_P, _P, _I, _Z, _I, _I, _P, _P, _P],
+    "ga_stft_loss_fwd_mode": [_P, _P, _I, _Z, _I, _I, _P, _I, _P],
+    "ga_stft_loss_bwd_mode": [_P, _P, _I, _Z, _I, _I, _P, _P, _I, _P],
     "ga_stft_unpad_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_lstm_fwd": [C.POINTER(LstmParams), _P],
     "ga_lstm_bwd": [C.POINTER(LstmBwdParams), _P],

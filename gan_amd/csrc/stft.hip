@@ -32,7 +32,7 @@ __global__ void stft_pad_kernel(const TI* __restrict__ x, TO* __restrict__ xp, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const T* __restrict__ sx, const T* __restrict__ sy, size_t frames, int nb,
-                                                             int ld, float* __restrict__ out) {
+                                                             int ld, float* __restrict__ out, int mag_add) {
     __shared__ float red[16];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const size_t n = frames * nb;
@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const T* __restrict_
         const int k = (int)(i % nb);
         const float xr = (float)sx[f * ld + k], xi = (float)sx[f * ld + nb + k];
         const float yr = (float)sy[f * ld + k], yi = (float)sy[f * ld + nb + k];
-        const float mx = fmaxf(sqrtf(xr * xr + xi * xi), 1e-8f);
-        const float my = fmaxf(sqrtf(yr * yr + yi * yi), 1e-8f);
+        // magnitude floor: clamp_min(1e-8) (lab3_codec_train.py:168-169) or + 1e-8 (lab3_losses.py:60-61)
+        const float ax = sqrtf(xr * xr + xi * xi), ay = sqrtf(yr * yr + yi * yi);
+        const float mx = mag_add ? ax + 1e-8f : fmaxf(ax, 1e-8f);
+        const float my = mag_add ? ay + 1e-8f : fmaxf(ay, 1e-8f);
         const float d = my - mx;
         s0 = fmaf(d, d, s0);
         s1 = fmaf(my, my, s1);
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const T* __restrict_
 
 template <typename T>
 __global__ void stft_loss_bwd_kernel(const T* __restrict__ sx, const T* __restrict__ sy, size_t frames, int nb, int ld,
-                                     const float* __restrict__ coef, T* __restrict__ dsx) {
+                                     const float* __restrict__ coef, T* __restrict__ dsx, int mag_add) {
     const float c0 = coef[0], c2 = coef[2];
     const size_t n = frames * (size_t)ld;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -72,10 +74,12 @@ __global__ void stft_loss_bwd_kernel(const T* __restrict__ sx, const T* __restri
             const float xr = (float)sx[f * ld + k], xi = (float)sx[f * ld + nb + k];
             const float yr = (float)sy[f * ld + k], yi = (float)sy[f * ld + nb + k];
             const float ax = sqrtf(xr * xr + xi * xi);
-            if (ax >= 1e-8f) {
-                const float my = fmaxf(sqrtf(yr * yr + yi * yi), 1e-8f);
-                const float dl = logf(ax) - logf(my);
-                const float dmx = c0 * 2.f * (ax - my) + c2 * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / ax;
+            const float ay = sqrtf(yr * yr + yi * yi);
+            if (mag_add ? ax > 0.f : ax >= 1e-8f) {  // (clamped bins and |X| = 0 pass no gradient)
+                const float mx = mag_add ? ax + 1e-8f : ax;
+                const float my = mag_add ? ay + 1e-8f : fmaxf(ay, 1e-8f);
+                const float dl = logf(mx) - logf(my);
+                const float dmx = c0 * 2.f * (mx - my) + c2 * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / mx;
                 g = dmx * (col < nb ? xr : xi) / ax;
             }
         }
@@ -126,29 +130,42 @@ int ga_stft_pad(const void* x, void* xp, int dtype_in, int dtype_out, int B, int
     return GA_OK;
 }
 
+int ga_stft_loss_fwd_mode(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, float* out, int mag_mode, hipStream_t s);
+int ga_stft_loss_bwd_mode(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, const float* coef, void* dsx,
+                          int mag_mode, hipStream_t s);
+
 int ga_stft_loss_fwd(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, float* out, hipStream_t s) {
-    if (!sx || !sy || !out || nb <= 0 || ld < 2 * nb) return GA_ERR_ARG;
+    return ga_stft_loss_fwd_mode(sx, sy, dtype, frames, nb, ld, out, GA_STFT_MAG_CLAMP, s);
+}
+
+int ga_stft_loss_bwd(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, const float* coef, void* dsx,
+                     hipStream_t s) {
+    return ga_stft_loss_bwd_mode(sx, sy, dtype, frames, nb, ld, coef, dsx, GA_STFT_MAG_CLAMP, s);
+}
+
+int ga_stft_loss_fwd_mode(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, float* out, int mag_mode, hipStream_t s) {
+    if (!sx || !sy || !out || nb <= 0 || ld < 2 * nb || (mag_mode != GA_STFT_MAG_CLAMP && mag_mode != GA_STFT_MAG_ADD)) return GA_ERR_ARG;
     if (frames == 0) return GA_OK;
     const size_t n = frames * nb;
     if (dtype == GA_DTYPE_BF16)
-        stft_loss_fwd_kernel<bf16_t><<<grid_for(n, 1024), 256, 0, s>>>((const bf16_t*)sx, (const bf16_t*)sy, frames, nb, ld, out);
+        stft_loss_fwd_kernel<bf16_t><<<grid_for(n, 1024), 256, 0, s>>>((const bf16_t*)sx, (const bf16_t*)sy, frames, nb, ld, out, mag_mode);
     else if (dtype == GA_DTYPE_F32)
-        stft_loss_fwd_kernel<float><<<grid_for(n, 1024), 256, 0, s>>>((const float*)sx, (const float*)sy, frames, nb, ld, out);
+        stft_loss_fwd_kernel<float><<<grid_for(n, 1024), 256, 0, s>>>((const float*)sx, (const float*)sy, frames, nb, ld, out, mag_mode);
     else
         return GA_ERR_ARG;
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
 
-int ga_stft_loss_bwd(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, const float* coef, void* dsx,
-                     hipStream_t s) {
-    if (!sx || !sy || !coef || !dsx || nb <= 0 || ld < 2 * nb) return GA_ERR_ARG;
+int ga_stft_loss_bwd_mode(const void* sx, const void* sy, int dtype, size_t frames, int nb, int ld, const float* coef, void* dsx,
+                          int mag_mode, hipStream_t s) {
+    if (!sx || !sy || !coef || !dsx || nb <= 0 || ld < 2 * nb || (mag_mode != GA_STFT_MAG_CLAMP && mag_mode != GA_STFT_MAG_ADD)) return GA_ERR_ARG;
     if (frames == 0) return GA_OK;
     const size_t n = frames * ld;
     if (dtype == GA_DTYPE_BF16)
-        stft_loss_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)sx, (const bf16_t*)sy, frames, nb, ld, coef, (bf16_t*)dsx);
+        stft_loss_bwd_kernel<bf16_t><<<grid_for(n), 256, 0, s>>>((const bf16_t*)sx, (const bf16_t*)sy, frames, nb, ld, coef, (bf16_t*)dsx, mag_mode);
     else if (dtype == GA_DTYPE_F32)
-        stft_loss_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)sx, (const float*)sy, frames, nb, ld, coef, (float*)dsx);
+        stft_loss_bwd_kernel<float><<<grid_for(n), 256, 0, s>>>((const float*)sx, (const float*)sy, frames, nb, ld, coef, (float*)dsx, mag_mode);
     else
         return GA_ERR_ARG;
     GA_CHECK_LAUNCH();

@@ -1166,7 +1166,8 @@ class StftSums(torch.autograd.Function):
     magnitude / log / reduction kernels are fp32 either way."""
 
     @staticmethod
-    def forward(ctx, x, y, n_fft: int, hop: int, win: int, split: bool):
+    def forward(ctx, x, y, n_fft: int, hop: int, win: int, split: bool, mag_add: bool = False):
+        """mag_add: magnitudes floored as |X| + 1e-8 (lab3_losses.multi_resolution_stft_loss) instead of clamp_min(1e-8)."""
         L.require_cuda(x, y)
         ctx.in_dtype = x.dtype
         x = x.contiguous().float()
@@ -1190,10 +1191,11 @@ class StftSums(torch.autograd.Function):
             _launch_conv(p, xp, w_f, spec, impl=_IMPL, alg_flops=2.0 * B * frames * n_fft * 2 * (n_fft // 2 + 1))
             specs.append(spec)
         out = zeros_f32(3, x.device)
-        L.check(lib.ga_stft_loss_fwd(specs[0].data_ptr(), specs[1].data_ptr(), L.DT_F32, B * frames, nb, M, out.data_ptr(),
-                                     L.stream()), "ga_stft_loss_fwd")
+        L.check(lib.ga_stft_loss_fwd_mode(specs[0].data_ptr(), specs[1].data_ptr(), L.DT_F32, B * frames, nb, M, out.data_ptr(),
+                                          1 if mag_add else 0, L.stream()), "ga_stft_loss_fwd_mode")
         ctx.save_for_backward(specs[0], specs[1], w_d)
         ctx.cfg = (B, S, n_fft, hop, rows, frames, nb, M, J, split)
+        ctx.mag_add = bool(mag_add)
         return out
 
     @staticmethod
@@ -1203,8 +1205,8 @@ class StftSums(torch.autograd.Function):
         lib = L.lib()
         gout = gout.contiguous().float()
         dsx = torch.empty_like(sx)
-        L.check(lib.ga_stft_loss_bwd(sx.data_ptr(), sy.data_ptr(), L.DT_F32, B * frames, nb, M, gout.data_ptr(), dsx.data_ptr(),
-                                     L.stream()), "ga_stft_loss_bwd")
+        L.check(lib.ga_stft_loss_bwd_mode(sx.data_ptr(), sy.data_ptr(), L.DT_F32, B * frames, nb, M, gout.data_ptr(), dsx.data_ptr(),
+                                          1 if ctx.mag_add else 0, L.stream()), "ga_stft_loss_bwd_mode")
         if split:
             dsx = dsx.to(torch.bfloat16)  # MFMA operand; accumulation and the output stay fp32
         p = _new_params()
@@ -1214,7 +1216,7 @@ class StftSums(torch.autograd.Function):
         dx = torch.empty((B, S), device=sx.device, dtype=torch.float32)
         L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.DT_F32, L.DT_F32, B, S, n_fft, hop, rows, 0, L.stream()),
                 "ga_stft_unpad_bwd")
-        return dx.to(ctx.in_dtype), None, None, None, None, None
+        return dx.to(ctx.in_dtype), None, None, None, None, None, None
 
 
 # ================================================================================================

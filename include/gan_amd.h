@@ -297,6 +297,14 @@ int ga_stft_loss_fwd(const void* spec_x, const void* spec_y, int dtype, size_t f
                      ga_stream_t stream);
 int ga_stft_loss_bwd(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec,
                      const float* coef, void* dspec_x, ga_stream_t stream);
+/* The same two kernels with the magnitude floor as a parameter: GA_STFT_MAG_CLAMP = |X|.clamp_min(1e-8) (the waveform loss
+ * above), GA_STFT_MAG_ADD = |X| + 1e-8 (the mel-trajectory sibling multi_resolution_stft_loss, lab 3/src/lab3_losses.py:16-71) */
+#define GA_STFT_MAG_CLAMP 0
+#define GA_STFT_MAG_ADD 1
+int ga_stft_loss_fwd_mode(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec, float* out,
+                          int mag_mode, ga_stream_t stream);
+int ga_stft_loss_bwd_mode(const void* spec_x, const void* spec_y, int dtype, size_t frames_total, int nb, int ldspec,
+                          const float* coef, void* dspec_x, int mag_mode, ga_stream_t stream);
 /* MR-STFT scalar tail (lab3_codec_train.py:161-176): out[0] = (1/R) sum_r [ sqrt(sums[r][0]) / (sqrt(sums[r][1]) + 1e-8)
  * + sums[r][2] * inv_count[r] ] (out != NULL) and/or dsums = gout[0] * d out / d sums (dsums != NULL).  R <= 64. */
 int ga_stft_combine(const float* sums, const float* inv_count, int R, const float* gout, float* out, float* dsums,

@@ -207,6 +207,28 @@ def waveform_mrstft_loss(wav_pred: Tensor, wav_true: Tensor, resolutions=DEFAULT
     return total / float(used)
 
 
+def mel_mrstft_loss(mel_pred: Tensor, mel_true: Tensor, resolutions=((64, 16, 64), (128, 32, 128), (256, 64, 256))) -> Tensor:
+    """lab 3/src/lab3_losses.py:16-71 (multi_resolution_stft_loss): the waveform loss's sibling on mel trajectories
+    [B, n_mels, T], magnitudes |X| + 1e-8; resolutions with n_fft > T are skipped; L1 fallback when none is used."""
+    if mel_pred.shape != mel_true.shape:
+        raise ValueError(f"Shape mismatch: {mel_pred.shape} vs {mel_true.shape}")
+    b, n_mels, t = mel_pred.shape
+    x, y = mel_pred.reshape(b * n_mels, t), mel_true.reshape(b * n_mels, t)
+    total, count = 0.0, 0
+    for n_fft, hop, win in resolutions:
+        if t < int(n_fft):
+            continue
+        window = torch.hann_window(int(win), dtype=x.dtype)
+        sx = torch.stft(x, n_fft=int(n_fft), hop_length=int(hop), win_length=int(win), window=window, return_complex=True, center=True)
+        sy = torch.stft(y, n_fft=int(n_fft), hop_length=int(hop), win_length=int(win), window=window, return_complex=True, center=True)
+        mx, my = sx.abs() + 1e-8, sy.abs() + 1e-8
+        total = total + torch.norm(my - mx, p="fro") / (torch.norm(my, p="fro") + 1e-8) + F.l1_loss(torch.log(mx), torch.log(my))
+        count += 1
+    if count == 0:
+        return F.l1_loss(mel_pred, mel_true)
+    return total / float(count)
+
+
 # ------------------------------------------------------------------------------------------------
 # frozen SEANet decoder (HF modeling_encodec.py, EncodecConfig() defaults = 24 kHz model)
 RATIOS = (8, 5, 4, 2)

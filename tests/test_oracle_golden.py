@@ -198,3 +198,23 @@ def test_mrstft_gradient_is_ill_conditioned_in_fp32(state):
     cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()))
     assert cos(g_grad(batch, 2.0), g_grad(pert, 2.0)) < 0.95
     assert cos(g_grad(batch, 0.0), g_grad(pert, 0.0)) > 0.999
+
+
+def test_mel_mrstft_sibling_matches_reference_golden():
+    """oracle.mel_mrstft_loss vs the reference's multi_resolution_stft_loss (lab3_losses.py:16-71; tests/golden/mel_golden.npz)."""
+    from pathlib import Path
+    with np.load(Path(__file__).resolve().parent / "golden" / "mel_golden.npz") as z:
+        gold = {k: z[k] for k in z.files}
+    x = proc_input((2, 96, 256), "mel.pred", 0, 0.8).requires_grad_(True)
+    y = proc_input((2, 96, 256), "mel.true", 0, 0.8)
+    l = O.mel_mrstft_loss(x, y)
+    assert float(l.detach()) == pytest.approx(float(gold["full"]), rel=1e-5)
+    g, = torch.autograd.grad(l, x)
+    np.testing.assert_allclose(g.numpy()[:, ::7, ::5], gold["full_grad"], rtol=1e-3, atol=1e-9)
+    assert float(O.mel_mrstft_loss(x[:, :, :100], y[:, :, :100]).detach()) == pytest.approx(float(gold["short100"]), rel=1e-5)
+    assert float(O.mel_mrstft_loss(x[:, :, :40], y[:, :, :40]).detach()) == pytest.approx(float(gold["fallback40"]), rel=1e-5)
+    z = torch.zeros(1, 4, 256)
+    z[0, 1, 30] = 1e-4
+    assert float(O.mel_mrstft_loss(z, y[:1, :4])) == pytest.approx(float(gold["silence"]), rel=1e-5)
+    with pytest.raises(ValueError):
+        O.mel_mrstft_loss(x, y[:, :, :100])
