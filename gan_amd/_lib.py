@@ -17,11 +17,13 @@ DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_ELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3, 4
 DACT_NONE, DACT_LRELU_FROM_OUT, DACT_ELU_FROM_IN = 0, 1, 2
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_WINDOW, IMPL_MFMA_PP, IMPL_MFMA_LDSWIN = 0, 1, 2, 3, 4, 5
+IMPL_MFMA_STREAM, IMPL_MFMA_STREAMWIN = 6, 7
 KERNEL_GEMM_64x256, KERNEL_GEMM_128x128, KERNEL_GEMM_32x256 = 7, 8, 9
 KERNEL_STREAM = 10
 KERNEL_GEMM_PP = 11
 KERNEL_CONV_WIN = 12
-GEMM_KERNELS = (7, 8, 9, 10, 11, 12)  # MFMA kernels whose operands never pass through a conv window in LDS
+KERNEL_STREAM_WIN = 13
+GEMM_KERNELS = (7, 8, 9, 10, 11, 12, 13)  # MFMA kernels whose operands never pass through a conv window in LDS
 PACK_CONV_FWD, PACK_CONV_DGRAD_S1, PACK_CONV_DGRAD_STRIDED, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3, 4
 RED_ABSDIFF, RED_RELU1M, RED_RELU1P, RED_SUM, RED_SQ = 0, 1, 2, 3, 4
 

@@ -18,6 +18,9 @@ int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_stream_supported(const ConvParams& p);
 int ga_conv_stream_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_swin_supported(const ConvParams& p);
+int ga_conv_swin_wanted(const ConvParams& p);
+int ga_conv_swin_impl(const ConvParams& p, hipStream_t s);
 int ga_wgrad_mfma_supported(const WgradParams& p);
 int ga_wgrad_mfma_impl(const WgradParams& p, hipStream_t s);
 int ga_wgrad_gemm_supported(const WgradParams& p);
@@ -41,9 +44,12 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     const bool can_gemm = dtype == GA_DTYPE_BF16 && ga_conv_gemm_supported(p);
     if (impl == GA_IMPL_MFMA_PP) return (dtype == GA_DTYPE_BF16 && ga_conv_pp_supported(p)) ? ga_conv_pp_impl(p, s) : GA_ERR_ARG;
     if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? ga_conv_win_impl(p, s) : GA_ERR_ARG;
-    // thin bf16 layers (M <= 64, K <= 192): the register-streaming MFMA kernel, which is also the one that fuses ELU(x)
+    if (impl == GA_IMPL_MFMA_STREAM) return (dtype == GA_DTYPE_BF16 && ga_conv_stream_supported(p)) ? ga_conv_stream_impl(p, s) : GA_ERR_ARG;
+    if (impl == GA_IMPL_MFMA_STREAMWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_swin_supported(p)) ? ga_conv_swin_impl(p, s) : GA_ERR_ARG;
+    // thin bf16 layers (M <= 64, K <= 192): the streaming MFMA kernels, which are also the ones that fuse ELU(x) -- multi-tap
+    // layers through a per-wave LDS window ring, the rest straight from global memory into the operand registers
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
-        return ga_conv_stream_impl(p, s);
+        return ga_conv_swin_wanted(p) ? ga_conv_swin_impl(p, s) : ga_conv_stream_impl(p, s);
     if (p.res_mode != GA_RES_ADD) {  // only the gathered-GEMM kernel's epilogue forms the feature-matching term
         if (p.res_mode != GA_RES_FM_SIGN || !p.res || !p.dact_src || !p.dact_mode || !p.res_coef_dev) return GA_ERR_ARG;
         return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
@@ -90,6 +96,8 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     const bool big = (long)p.Lout * p.B >= 64 || p.out_f32;
     if (impl == GA_IMPL_MFMA_PP) return (dtype == GA_DTYPE_BF16 && ga_conv_pp_supported(p)) ? GA_KERNEL_GEMM_PP : -1;
     if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? GA_KERNEL_CONV_WIN : -1;
+    if (impl == GA_IMPL_MFMA_STREAM) return (dtype == GA_DTYPE_BF16 && ga_conv_stream_supported(p)) ? GA_KERNEL_STREAM : -1;
+    if (impl == GA_IMPL_MFMA_STREAMWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_swin_supported(p)) ? GA_KERNEL_STREAM_WIN : -1;
     if (p.res_mode != GA_RES_ADD) {  // ga_conv: gathered-GEMM kernel or nothing
         if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
         if (ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
@@ -97,7 +105,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
         return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
     }
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
-        return GA_KERNEL_STREAM;
+        return ga_conv_swin_wanted(p) ? GA_KERNEL_STREAM_WIN : GA_KERNEL_STREAM;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;

@@ -135,7 +135,7 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
             assert t.is_contiguous() and t.dtype == y.dtype and t.numel() == y.numel()
     p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     p.bias, p.res, p.dact_src = L.ptr(bias), L.ptr(res), L.ptr(dact_src)
-    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_PP, L.IMPL_MFMA_LDSWIN):
+    if MERGE_PHASES and impl in (L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_PP, L.IMPL_MFMA_LDSWIN, L.IMPL_MFMA_STREAM, L.IMPL_MFMA_STREAMWIN):
         p, bias = _fold_phases(p, x, bias)
     # few output tiles x deep K (D blocks 3-4): split K over workgroups, one fp32 partial-sum slab per slice
     ks = L.lib().ga_conv_suggest_ksplit(C.byref(p), L.dt(x), impl) if SPLIT_K else 1
@@ -823,14 +823,14 @@ def act_fwd(x: Tensor, act: int) -> Tensor:
 
 
 def _streams_with_pre_act(g: ConvGeom, x: Tensor, pre_act: int) -> bool:
-    """True when ga_conv would run this forward, input activation included, on the register-streaming MFMA kernel."""
+    """True when ga_conv would run this forward, input activation included, on one of the streaming MFMA kernels."""
     if _IMPL not in (L.IMPL_AUTO, L.IMPL_MFMA):
         return False
     p = fwd_params(g, x.shape[0], x.shape[1])
     p.pre_act = pre_act
     if MERGE_PHASES:
         p, _ = _fold_phases(p, x, None)
-    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) == L.KERNEL_STREAM
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) in (L.KERNEL_STREAM, L.KERNEL_STREAM_WIN)
 
 
 class ConvFrozen(torch.autograd.Function):

@@ -56,6 +56,9 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 #define GA_IMPL_MFMA_LDSWIN 5 /* force the LDS-window kernel of the narrow-channel D layers (conv_win_kernel: the input rows of a
                                  tile staged once in LDS, every tap read from there); error if unsupported.  AUTO / MFMA pick it
                                  for Cin 32 / stride 4 (D blocks.1 forward) and Cin 64 / stride 1 (its folded data gradient) */
+#define GA_IMPL_MFMA_STREAM 6    /* force the register-streaming kernel of the thin layers (conv_stream_kernel); error if unsupported */
+#define GA_IMPL_MFMA_STREAMWIN 7 /* force the streaming-window kernel of the thin multi-tap layers (conv_swin_kernel: a per-wave ring
+                                    of input windows in LDS); error if unsupported.  AUTO / MFMA pick it for long launches */
 
 #define GA_MAX_PHASE 8
 
@@ -152,6 +155,7 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_STREAM 10      /* conv_stream_kernel: M <= 64, K <= 192, operands straight from global memory */
 #define GA_KERNEL_GEMM_PP 11     /* conv_pp_kernel: 256x256 tiles, wave tile 128x64, ping-pong schedule (deep K, M >= 192) */
 #define GA_KERNEL_CONV_WIN 12    /* conv_win_kernel: input window in LDS, weights streamed (narrow-channel D layers) */
+#define GA_KERNEL_STREAM_WIN 13  /* conv_swin_kernel: M <= 64, 2-4 taps, weights in registers, per-wave ring of input windows in LDS */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]

@@ -3,6 +3,8 @@
 fp32 mode (direct kernels): rtol 1e-4 (relative to the tensor's max), the north-star fp32 bound.
 bf16 mode (MFMA kernels): inputs/weights rounded to bf16, fp32 accumulate: 2e-2 of the tensor's max.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -870,6 +872,45 @@ def test_lds_window_kernel_matches_gathered_and_direct_kernels():
         if outs["window"][1] is not None:
             assert torch.equal(outs["window"][1], outs["gather"][1]), g
             close(outs["window"][1], outs["direct"][1], 1e-2, f"window dgrad {g} L={Ln}")
+
+
+def test_streaming_window_kernel_matches_register_streaming_and_direct_kernels():
+    """conv_swin_kernel (per-wave ring of input windows in LDS, ELU once per element in place) on the three forms it takes:
+    the decoder's k=3 residual convs at 64 and 32 input channels (causal reflect padding at the left edge) and the k=2s
+    transposed conv with its two output phases folded into 64 channels; ragged last tiles, items shorter than one tile, fewer
+    output channels than a 32-row MFMA tile, an odd output length behind the fold, with and without ELU, enough tiles that
+    every wave walks its ring more than once.  Same bf16 operands, ELU arithmetic and fp32 accumulation order as
+    conv_stream_kernel: equal to the last bit; the direct kernel bounds both."""
+    torch.manual_seed(34)
+    cases = ((ConvGeom("cconv", 64, 32, 3), 4097, 3), (ConvGeom("cconv", 64, 32, 3), 70, 2), (ConvGeom("cconv", 64, 24, 3), 1500, 2),
+             (ConvGeom("cconv", 32, 16, 3), 9001, 3), (ConvGeom("cconv", 32, 16, 3), 127, 1), (ConvGeom("cconv", 32, 32, 3), 300, 2),
+             (ConvGeom("convt", 64, 32, 4, 2), 2049, 3), (ConvGeom("convt", 64, 32, 4, 2), 31, 2), (ConvGeom("convt", 64, 16, 4, 2), 777, 2),
+             (ConvGeom("cconv", 64, 32, 3), 60000, 40))
+    for g, Ln, B in cases:
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        wf = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16)
+        for pre in (L.ACT_ELU, L.ACT_NONE):
+            outs = {}
+            for name, impl in (("swin", L.IMPL_MFMA_STREAMWIN), ("stream", L.IMPL_MFMA_STREAM), ("direct", L.IMPL_DIRECT)):
+                if name == "direct" and Ln > 10000:
+                    continue
+                ops.set_conv_impl(impl)
+                try:
+                    outs[name] = ops.conv_forward(g, x, wf, bias, pre_act=pre).float().cpu()
+                finally:
+                    ops.set_conv_impl(L.IMPL_AUTO)
+            assert torch.equal(outs["swin"], outs["stream"]), (g, Ln, pre)
+            if "direct" in outs:
+                close(outs["swin"], outs["direct"], 1.5e-2, f"swin {g} L={Ln} pre={pre}")
+    # AUTO picks it for the long ELU launches only
+    p = ops.fwd_params(ConvGeom("cconv", 64, 32, 3), 64, 60000)
+    p.x = p.w = p.y = 256
+    p.pre_act = L.ACT_ELU
+    assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM_WIN
+    p.pre_act = L.ACT_NONE
+    assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM
 
 
 def test_pack_cache_is_released_with_its_optimizer():
