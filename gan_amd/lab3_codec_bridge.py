@@ -14,6 +14,8 @@ decoder's, so `SeanetDecoder.load_state_dict(hf_model.decoder.state_dict())` is 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -82,6 +84,7 @@ class SeanetDecoder(nn.Module):
         super().__init__()
         self.precision = precision
         self.use_library_lstm = False  # True: torch's LSTM op (MIOpen) instead of the gan_amd step kernels (A/B checks)
+        self.fuse_resblock = os.environ.get("GA_FUSE_RESBLOCK", "1") != "0"  # False: a residual unit as three autograd nodes (A/B checks)
         self.ratios = tuple(int(r) for r in ratios)
         c = (2 ** len(self.ratios)) * num_filters
         layers = nn.Module()
@@ -180,9 +183,16 @@ class SeanetDecoder(nn.Module):
             elif kind == "elu_convt":
                 h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
             elif kind == "resblock":
-                sc = self._conv(name + ".sc", layer.shortcut, h, dtype)
-                t = self._conv(name + ".b1", getattr(layer.block, "1"), h, dtype, pre_act=L.ACT_ELU)
-                h = self._conv(name + ".b3", getattr(layer.block, "3"), t, dtype, pre_act=L.ACT_ELU, res=sc)
+                b1, b3 = getattr(layer.block, "1"), getattr(layer.block, "3")
+                if h.dtype == torch.bfloat16 and self.fuse_resblock:  # one autograd node: no gradient-sum pass over h
+                    h = ops.ResBlockFrozen.apply(
+                        h, *self._pack(name + ".sc", layer.shortcut, dtype), layer.shortcut.conv.bias.data, layer.shortcut.geom,
+                        *self._pack(name + ".b1", b1, dtype), b1.conv.bias.data, b1.geom,
+                        *self._pack(name + ".b3", b3, dtype), b3.conv.bias.data, b3.geom)
+                else:
+                    sc = self._conv(name + ".sc", layer.shortcut, h, dtype)
+                    t = self._conv(name + ".b1", b1, h, dtype, pre_act=L.ACT_ELU)
+                    h = self._conv(name + ".b3", b3, t, dtype, pre_act=L.ACT_ELU, res=sc)
             elif kind == "elu_conv":
                 # the waveform leaves the decoder in fp32 even in bf16 mode: the MR-STFT log-magnitude loss reads it
                 h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU, out_f32=True)

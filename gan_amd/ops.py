@@ -833,6 +833,43 @@ def _streams_with_pre_act(g: ConvGeom, x: Tensor, pre_act: int) -> bool:
     return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) in (L.KERNEL_STREAM, L.KERNEL_STREAM_WIN)
 
 
+def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int, res=None, out_f32: bool = False) -> Tensor:
+    if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and not _streams_with_pre_act(geom, x, pre_act):
+        # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
+        # which cannot transform its operand in flight (the thin layers' streaming kernels can: no copy there)
+        return conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, res=None if res is None else res.contiguous(), out_f32=out_f32)
+    return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
+
+
+class ResBlockFrozen(torch.autograd.Function):
+    """SEANet residual unit with frozen weights (HF modeling_encodec.py:320-343: shortcut(x) + conv_k1(ELU(conv_k(ELU(x))))) as ONE
+    autograd node.  As three ConvFrozen nodes, autograd sums the two gradients that reach x (shortcut and block) with an
+    element-wise pass over the unit's input -- the largest activations of the step; here the shortcut's data-gradient launch
+    takes the block's gradient as its residual operand and adds it in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, sc_f, sc_d, sc_b, g_sc: ConvGeom, b1_f, b1_d, b1_b, g1: ConvGeom, b3_f, b3_d, b3_b, g3: ConvGeom):
+        x = x.contiguous()
+        sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
+        t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU)
+        y = _frozen_forward(g3, t, b3_f, b3_b, L.ACT_ELU, res=sc)
+        ctx.geoms = (g_sc, g1, g3)
+        ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, t, sc_d, b1_d, b3_d = ctx.saved_tensors
+        g_sc, g1, g3 = ctx.geoms
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gy = gy.contiguous().to(x.dtype)
+            gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=t)
+            gb = conv_dgrad(g1, gt, b1_d, x.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
+            gx = conv_dgrad(g_sc, gy, sc_d, x.shape[1], res=gb)
+        return (gx,) + (None,) * 12
+
+
 class ConvFrozen(torch.autograd.Function):
     """y = conv(pre_act(x)) + bias (+ res) with frozen weights (SEANet decoder): only dx is produced.
     dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
@@ -840,12 +877,7 @@ class ConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False):
         x = x.contiguous()
-        if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and not _streams_with_pre_act(geom, x, pre_act):
-            # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
-            # which cannot transform its operand in flight (the thin layers' streaming kernel can: no copy there)
-            y = conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, res=None if res is None else res.contiguous(), out_f32=out_f32)
-        else:
-            y = conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
+        y = _frozen_forward(geom, x, wp_f, bias, pre_act, res, out_f32)
         ctx.geom, ctx.pre_act = geom, pre_act
         ctx.x_dtype = x.dtype
         ctx.save_for_backward(x if pre_act else None, wp_d)

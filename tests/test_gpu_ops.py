@@ -913,6 +913,28 @@ def test_streaming_window_kernel_matches_register_streaming_and_direct_kernels()
     assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM
 
 
+def test_fused_residual_unit_matches_three_node_form():
+    """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
+    block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
+    the last bit, gradient equal up to the one bf16 rounding the separate sum adds."""
+    from gan_amd.lab3_codec_bridge import SeanetDecoder
+    torch.manual_seed(35)
+    dec = SeanetDecoder(precision="bf16").to(DEV)
+    for p_ in dec.parameters():
+        p_.data.normal_(0.0, 0.05)
+    dec.invalidate_packs()
+    q = torch.randn(2, 128, 9, device=DEV)
+    outs = {}
+    for fused in (True, False):
+        dec.fuse_resblock = fused
+        qq = q.clone().requires_grad_(True)
+        wav = dec(qq)
+        g, = torch.autograd.grad(wav.float().square().sum(), qq)
+        outs[fused] = (wav.detach().float().cpu(), g.float().cpu())
+    assert torch.equal(outs[True][0], outs[False][0])
+    close(outs[True][1], outs[False][1], 2e-2, "fused residual unit dq")
+
+
 def test_pack_cache_is_released_with_its_optimizer():
     """Packed weights are cached per optimizer epoch; when the FusedAdamW that owns the parameter buffer is dropped (one per
     train_codec_stage call), its packs and its epoch range go with it instead of staying resident for the life of the process."""
