@@ -13,6 +13,9 @@
 //   LDS rows are 256 B; the 64-byte quarter q of row r is stored at quarter q ^ (r & 3), so the four rows one
 //   transposing read touches land on different bank quarters (conflict-free); the XOR sits on the SOURCE piece.
 //   The reduction range is split over gridDim.y; partial tiles are added with fp32 atomics (128-byte row segments).
+//   M <= 64 (D blocks.1): the block tile is 64 (m) x 256 (k) instead -- one G tile, TWO gathered-X tiles of 128 columns, the four
+//   waves side by side along k -- so that a reduction step carries the same 16 MFMAs per wave as the 128 x 128 tile does (with
+//   the 128 x 128 tile half of the G tile was padding and every wave had 8 MFMAs per barrier pair: half the rate).
 #include "common.h"
 #include <stdlib.h>
 
@@ -52,18 +55,19 @@ static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0
 // NBUF = 2: next step's loads in flight behind the current multiply (64 KiB of LDS, two workgroups per CU).
 // NBUF = 1: one buffer, 32 KiB, 128 registers: four workgroups per CU hide each other's load round trips (the form that won for
 //           the forward kernel on grids several workgroups per CU deep).
-template <int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
+// NB = number of 128-column gathered-X tiles per workgroup: 1 (128 x 128 block tile) or 2 (64 x 256, M <= 64 only)
+template <int NBUF, int NB>
+__global__ __launch_bounds__(256, NBUF == 1 ? (NB == 1 ? 4 : 3) : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const Al = smem;                    // [NBUF][64][256 B]  G rows
-    char* const Bl = smem + NBUF * WGG_TILE;  // [NBUF][64][256 B]  gathered X rows
+    char* const Bl = smem + NBUF * WGG_TILE;  // [NBUF][NB][64][256 B]  gathered X rows
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
     const int g4 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int kt = blockIdx.x % ktiles, mt = blockIdx.x / ktiles;
-    const int mbase = mt * 128, kbase = kt * 128;
+    const int mbase = mt * 128, kbase = kt * 128 * NB;
     const int S = p.in_stride, Cin = p.Cin;
     const uintptr_t zero = (uintptr_t)ga_zero_page;
 
@@ -77,14 +81,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     const int lpiece = (lane & 15) ^ (prow << 2);  // logical piece held by this lane's slot (row & 3 == prow)
     const int am = mbase + lpiece * 8;
     const bool a_ok = am < p.M;
-    const int bk = kbase + lpiece * 8;
-    const bool b_ok = bk < Ktot;
-    const bool b_one = p.dbias && bk == Ktot;  // the bias column (fused only without slabs: see ga_wgrad_gemm_impl)
     const uintptr_t one = (uintptr_t)wgg_one_page;
     const int Kcols = Ktot + (p.dbias ? 1 : 0);
-    const int bj = b_ok ? bk / Cin : 0;
-    const int bc = b_ok ? bk - bj * Cin : 0;
-    const int bdR = bj * p.tap_step + p.off0;
+    bool b_ok[NB], b_one[NB];
+    int bc[NB], bdR[NB];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) {
+        const int bk = kbase + sb * 128 + lpiece * 8;
+        b_ok[sb] = bk < Ktot;
+        b_one[sb] = p.dbias && bk == Ktot;  // the bias column (fused only without slabs: see ga_wgrad_gemm_impl)
+        const int bj = b_ok[sb] ? bk / Cin : 0;
+        bc[sb] = b_ok[sb] ? bk - bj * Cin : 0;
+        bdR[sb] = bj * p.tap_step + p.off0;
+    }
     // per-row running (b, t) for the 4 rows this lane stages
     int rb[4], rt[4];
 #pragma unroll
@@ -98,15 +107,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
 
     auto issue = [&](int buf) {
         char* const ab = Al + buf * WGG_TILE + wid * 1024;
-        char* const bb = Bl + buf * WGG_TILE + wid * 1024;
+        char* const bb = Bl + buf * NB * WGG_TILE + wid * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool n_ok = rb[i] < p.B;
             const uintptr_t asrc = (uintptr_t)(g + ((size_t)rb[i] * p.LgTot + rt[i]) * p.M + am);
             wg_glds16(wg_sel(n_ok && a_ok, asrc, zero), ab + i * 4096);
-            const int R = rt[i] * S + bdR;
-            const uintptr_t bsrc = (uintptr_t)(x + ((size_t)rb[i] * p.Lin + R) * Cin + bc);
-            wg_glds16(wg_sel(b_one, one, wg_sel(n_ok && b_ok && R >= 0 && R < p.Lin, bsrc, zero)), bb + i * 4096);
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) {
+                const int R = rt[i] * S + bdR[sb];
+                const uintptr_t bsrc = (uintptr_t)(x + ((size_t)rb[i] * p.Lin + R) * Cin + bc[sb]);
+                wg_glds16(wg_sel(b_one[sb], one, wg_sel(n_ok && b_ok[sb] && R >= 0 && R < p.Lin, bsrc, zero)), bb + sb * WGG_TILE + i * 4096);
+            }
             // advance this row by one reduction step
             rt[i] += WGG_RK;
             while (rt[i] >= p.Lout) { rt[i] -= p.Lout; ++rb[i]; }
@@ -125,8 +137,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     // fragment; element column e -> logical piece e>>3, byte (e&7)*2; physical piece = logical ^ ((row&3)<<2), row&3 == q
     // M <= 64: only the first 64 rows of the 128-row tile exist.  Instead of idling, waves wm = 1 take the second half
     // of every 64-row reduction step for the SAME 64 x 64 output sub-tile (the partial sums meet in the atomics).
-    const bool halfm = p.M <= 64;
-    const int wme = halfm ? 0 : wm;
+    // (NB = 2: all four waves work on the 64 rows, side by side along k -- waves wm = 1 on the second X tile -- over the whole step)
+    const bool halfm = NB == 1 && p.M <= 64;
+    const int wme = (halfm || NB == 2) ? 0 : wm;
+    const int bsub = NB == 2 ? wm : 0;
     const int kk0 = halfm ? wm * 2 : 0, kk1 = halfm ? wm * 2 + 2 : 4;
     const int ecolA[2] = {wme * 64 + 16 * (g4 & 1) + 4 * pp, wme * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
     const int ecolB[2] = {wn * 64 + 16 * (g4 & 1) + 4 * pp, wn * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         offA[i] = ((((ecolA[i] >> 3) ^ (q << 2)) << 4) | ((ecolA[i] & 7) << 1)) + (8 * h + q) * 256;
         offB[i] = ((((ecolB[i] >> 3) ^ (q << 2)) << 4) | ((ecolB[i] & 7) << 1)) + (8 * h + q) * 256;
     }
-    const bool wave_active = (mbase + wme * 64) < p.M && (kbase + wn * 64) < Kcols;
+    const bool wave_active = (mbase + wme * 64) < p.M && (kbase + bsub * 128 + wn * 64) < Kcols;
 
     if (NBUF == 2 && s_begin < s_end) issue(0);
     for (int st = s_begin; st < s_end; ++st) {
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         if (NBUF == 2 && st + 1 < s_end) issue(buf ^ 1);
         if (wave_active) {
             const char* Ab = Al + buf * WGG_TILE;
-            const char* Bb = Bl + buf * WGG_TILE;
+            const char* Bb = Bl + (buf * NB + bsub) * WGG_TILE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 if (kk < kk0 || kk >= kk1) continue;
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     if (!wave_active) return;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int k = kbase + wn * 64 + ni * 32 + r;
+        const int k = kbase + bsub * 128 + wn * 64 + ni * 32 + r;
         if (k >= Kcols) continue;
         if (k == Ktot) {  // bias column
 #pragma unroll
@@ -228,11 +242,22 @@ static long wgg_target_blocks() {
     return v;
 }
 
+// 64 x 256 block tiles for M <= 64 (GA_WGRAD_WIDE64=0: the 128 x 128 tile for every layer)
+static bool wgg_wide64(const WgradParams& p) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("GA_WGRAD_WIDE64");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on && p.M <= 64;
+}
+
 static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles) {
     const int Ktot = p.J * p.Cin + (p.dbias ? 8 : 0);  // (+ one 16-byte piece for the bias column)
     const long Ntot = (long)p.B * p.Lout;
     const int mtiles = (p.M + 127) / 128;
-    ktiles = (Ktot + 127) / 128;
+    const int kw = wgg_wide64(p) ? 256 : 128;
+    ktiles = (Ktot + kw - 1) / kw;
     base = (long)mtiles * ktiles;
     nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
     splits = (wgg_target_blocks() + base - 1) / base;  // workgroups aimed for
@@ -279,17 +304,19 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
         const char* e = getenv("GA_WGRAD_NBUF");
         nbuf = (e && e[0] == '2') ? 2 : 1;  // single buffer by default: 20-40 % faster on every D layer (B = 24 and 128)
     }
-    if (nbuf == 1) {
-        wgrad_gemm_kernel<1><<<dim3((unsigned)base, (unsigned)splits), 256, 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    if (wgg_wide64(p)) {
+        wgrad_gemm_kernel<1, 2><<<dim3((unsigned)base, (unsigned)splits), 256, 3 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+    } else if (nbuf == 1) {
+        wgrad_gemm_kernel<1, 1><<<dim3((unsigned)base, (unsigned)splits), 256, 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
     } else {
         const size_t lds = 4 * WGG_TILE;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return GA_ERR_LAUNCH;
             attr_set = true;
         }
-        wgrad_gemm_kernel<2><<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+        wgrad_gemm_kernel<2, 1><<<dim3((unsigned)base, (unsigned)splits), 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
     }
     GA_CHECK_LAUNCH();
     if (p.ws) {
