@@ -57,10 +57,13 @@ static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0
 //           the forward kernel on grids several workgroups per CU deep).
 // NB = number of 128-column gathered-X tiles per workgroup: 1 (128 x 128 block tile) or 2 (64 x 256, M <= 64 only)
 template <int NBUF, int NB>
-__global__ __launch_bounds__(256, NBUF == 1 ? (NB == 1 ? 4 : 3) : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* const Al = smem;                    // [NBUF][64][256 B]  G rows
-    char* const Bl = smem + NBUF * WGG_TILE;  // [NBUF][NB][64][256 B]  gathered X rows
+    // NB = 2: the G tile has 64 columns; reduction rows n and n + 32 share one 256-byte LDS row (n + 32 in its second half), so
+    // the tile is 8 KiB, the row structure the transposing reads and their swizzle rely on stays, and four workgroups fit a CU
+    constexpr int ATILE = NB == 2 ? WGG_TILE / 2 : WGG_TILE;
+    char* const Al = smem;                    // [NBUF][64][256 B]  G rows   (NB = 2: [32][256 B])
+    char* const Bl = smem + NBUF * ATILE;     // [NBUF][NB][64][256 B]  gathered X rows
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -106,13 +109,25 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NB == 1 ? 4 : 3) : 1) void wgrad_
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
 
     auto issue = [&](int buf) {
-        char* const ab = Al + buf * WGG_TILE + wid * 1024;
+        char* const ab = Al + buf * ATILE + wid * 1024;
         char* const bb = Bl + buf * NB * WGG_TILE + wid * 1024;
+        if (NB == 2) {  // LDS row rho = i*16 + wid*4 + prow: pieces 0-7 = columns of reduction row rho, pieces 8-15 = of row rho + 32
+            const bool up = lpiece >= 8;
+            const int am2 = (lpiece & 7) * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int b_ = up ? rb[i + 2] : rb[i], t_ = up ? rt[i + 2] : rt[i];
+                const uintptr_t asrc = (uintptr_t)(g + ((size_t)b_ * p.LgTot + t_) * p.M + am2);
+                wg_glds16(wg_sel(b_ < p.B && am2 < p.M, asrc, zero), ab + i * 4096);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool n_ok = rb[i] < p.B;
-            const uintptr_t asrc = (uintptr_t)(g + ((size_t)rb[i] * p.LgTot + rt[i]) * p.M + am);
-            wg_glds16(wg_sel(n_ok && a_ok, asrc, zero), ab + i * 4096);
+            if (NB == 1) {
+                const uintptr_t asrc = (uintptr_t)(g + ((size_t)rb[i] * p.LgTot + rt[i]) * p.M + am);
+                wg_glds16(wg_sel(n_ok && a_ok, asrc, zero), ab + i * 4096);
+            }
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) {
                 const int R = rt[i] * S + bdR[sb];
@@ -144,11 +159,13 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NB == 1 ? 4 : 3) : 1) void wgrad_
     const int kk0 = halfm ? wm * 2 : 0, kk1 = halfm ? wm * 2 + 2 : 4;
     const int ecolA[2] = {wme * 64 + 16 * (g4 & 1) + 4 * pp, wme * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
     const int ecolB[2] = {wn * 64 + 16 * (g4 & 1) + 4 * pp, wn * 64 + 32 + 16 * (g4 & 1) + 4 * pp};
-    int offA[2], offB[2];
+    int offA[2], offB[2], offA2[2];  // offA2: the same fragment of reduction rows + 32 (NB = 2: second half of the LDS row)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         offA[i] = ((((ecolA[i] >> 3) ^ (q << 2)) << 4) | ((ecolA[i] & 7) << 1)) + (8 * h + q) * 256;
         offB[i] = ((((ecolB[i] >> 3) ^ (q << 2)) << 4) | ((ecolB[i] & 7) << 1)) + (8 * h + q) * 256;
+        const int e2 = ecolA[i] + 64;
+        offA2[i] = ((((e2 >> 3) ^ (q << 2)) << 4) | ((e2 & 7) << 1)) + (8 * h + q) * 256;
     }
     const bool wave_active = (mbase + wme * 64) < p.M && (kbase + bsub * 128 + wn * 64) < Kcols;
 
@@ -163,14 +180,17 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NB == 1 ? 4 : 3) : 1) void wgrad_
         __syncthreads();
         if (NBUF == 2 && st + 1 < s_end) issue(buf ^ 1);
         if (wave_active) {
-            const char* Ab = Al + buf * WGG_TILE;
+            const char* Ab = Al + buf * ATILE;
             const char* Bb = Bl + (buf * NB + bsub) * WGG_TILE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 if (kk < kk0 || kk >= kk1) continue;
                 bf16x8 a[2], b[2];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = wg_tr_frag(Ab + kk * 4096 + offA[mi], Ab + kk * 4096 + offA[mi] + 1024);
+                for (int mi = 0; mi < 2; ++mi) {
+                    const char* ap = NB == 2 ? Ab + (kk & 1) * 4096 + (kk < 2 ? offA[mi] : offA2[mi]) : Ab + kk * 4096 + offA[mi];
+                    a[mi] = wg_tr_frag(ap, ap + 1024);
+                }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) b[ni] = wg_tr_frag(Bb + kk * 4096 + offB[ni], Bb + kk * 4096 + offB[ni] + 1024);
 #pragma unroll
@@ -305,7 +325,7 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
         nbuf = (e && e[0] == '2') ? 2 : 1;  // single buffer by default: 20-40 % faster on every D layer (B = 24 and 128)
     }
     if (wgg_wide64(p)) {
-        wgrad_gemm_kernel<1, 2><<<dim3((unsigned)base, (unsigned)splits), 256, 3 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
+        wgrad_gemm_kernel<1, 2><<<dim3((unsigned)base, (unsigned)splits), 256, WGG_TILE / 2 + 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
     } else if (nbuf == 1) {
         wgrad_gemm_kernel<1, 1><<<dim3((unsigned)base, (unsigned)splits), 256, 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps);
     } else {
