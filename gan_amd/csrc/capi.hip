@@ -50,6 +50,9 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     // layers through a per-wave LDS window ring, the rest straight from global memory into the operand registers
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_swin_wanted(p) ? ga_conv_swin_impl(p, s) : ga_conv_stream_impl(p, s);
+    // single-output-channel thin layers, long launches: the streaming-window kernel's dot-product form
+    if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && p.res_mode == GA_RES_ADD && ga_conv_swin_wanted(p))
+        return ga_conv_swin_impl(p, s);
     if (p.res_mode != GA_RES_ADD) {  // only the gathered-GEMM kernel's epilogue forms the feature-matching term
         if (p.res_mode != GA_RES_FM_SIGN || !p.res || !p.dact_src || !p.dact_mode || !p.res_coef_dev) return GA_ERR_ARG;
         return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
@@ -104,6 +107,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
         if (ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
         return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
     }
+    if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && ga_conv_swin_wanted(p)) return GA_KERNEL_STREAM_WIN;
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_swin_wanted(p) ? GA_KERNEL_STREAM_WIN : GA_KERNEL_STREAM;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;

@@ -150,6 +150,38 @@ __global__ __launch_bounds__(256) void conv_cin1_vec_kernel(ConvParams p) {
 //
 // M <= 4: block = 256 consecutive output steps of one (batch item, phase); LDS rows are padded to an odd number of
 // 16-byte slots so that the lanes' ds_read_b128 of consecutive rows do not collide.
+typedef unsigned int fo_u32x4 __attribute__((ext_vector_type(4)));
+typedef float fo_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 fo_bf16x2;
+
+// ELU on eight packed bf16: f > -2^-12 returns f (ELU(f) = f there within half a bf16 step), else exp(f) - 1; two elements per
+// step so that the multiply / add / convert are packed instructions (the arithmetic of conv_stream.hip / conv_swin.hip)
+__device__ __forceinline__ fo_u32x4 fo_elu8(fo_u32x4 in) {
+    fo_u32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fo_f32x2 f;
+        f.x = __uint_as_float(in[i] << 16);
+        f.y = __uint_as_float(in[i] & 0xffff0000u);
+        const fo_f32x2 t = f * 1.4426950408889634f;
+        fo_f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(t.x);
+        e.y = __builtin_amdgcn_exp2f(t.y);
+        e = e - 1.0f;
+        union { fo_bf16x2 b; unsigned int u; } pk;
+        pk.b[0] = (__bf16)(f.x > -2.44140625e-4f ? f.x : e.x);
+        pk.b[1] = (__bf16)(f.y > -2.44140625e-4f ? f.y : e.y);
+        out[i] = pk.u;
+    }
+    return out;
+}
+__device__ __forceinline__ float fo_dot2(unsigned int a, unsigned int b, float c) {
+    union { unsigned int u; fo_bf16x2 v; } x, y;
+    x.u = a;
+    y.u = b;
+    return __builtin_amdgcn_fdot2_f32_bf16(x.v, y.v, c, false);  // v_dot2c_f32_bf16: c + a.lo*b.lo + a.hi*b.hi in fp32
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_fewout_lds_kernel(ConvParams p, int span, int pitch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -159,11 +191,70 @@ __global__ __launch_bounds__(256) void conv_fewout_lds_kernel(ConvParams p, int 
     const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
     const T* __restrict__ w = (const T*)p.w + (size_t)phase * p.M * KC;
     const T* __restrict__ x = (const T*)p.x + (size_t)b * p.Lin * p.Cin;
-    for (int i = threadIdx.x; i < p.M * KC; i += 256) wsm[i] = (float)w[i];
     const int off0 = p.off0 + p.phase_off0[phase];
     const int tblk = p.t0 + blockIdx.x * 256;
     const int R0 = tblk * p.in_stride + off0;
     const int parts = p.Cin / 8;
+    if constexpr (sizeof(T) == 2) {
+        // bf16, one output channel (decoder tail, D block 0 data gradient), no or ELU input activation: everything stays packed --
+        // 16-byte pieces straight into LDS (ELU on the packed pairs), the weights as bf16 pairs too, and the inner product by the
+        // packed dot instruction: 4 vector instructions per 8 channels where unpacking + eight FMAs took 16, which, not memory,
+        // set this kernel's pace (2.0-2.7 TB/s)
+        if (p.M == 1 && (p.pre_act == GA_ACT_NONE || p.pre_act == GA_ACT_ELU) && KC % 8 == 0 && ((uintptr_t)w & 15) == 0) {
+            fo_u32x4* wpk = (fo_u32x4*)smem_raw;                    // [J*Cin / 8] pieces of 8 bf16
+            for (int i = threadIdx.x; i < KC / 8; i += 256) wpk[i] = ((const fo_u32x4*)w)[i];
+            const bool elu = p.pre_act == GA_ACT_ELU;
+            // the window in rounds of eight pieces per thread, every load of a round issued before the first is used: one memory
+            // round trip per round, not per piece (a block has about five pieces per thread)
+            const fo_u32x4* const zp = (const fo_u32x4*)ga_zero_page;
+            for (int base = 0; base < span * parts; base += 8 * 256) {
+                fo_u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + threadIdx.x;
+                    const int row = idx / parts, part = idx - row * parts;
+                    int R = R0 + row;
+                    if (R < 0 && p.pad_mode == 1) R = -R;
+                    const bool ok = idx < span * parts && R >= 0 && R < p.Lin;
+                    v[u] = *(ok ? (const fo_u32x4*)(x + (size_t)R * p.Cin + part * 8) : zp);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + threadIdx.x;
+                    const int row = idx / parts, part = idx - row * parts;
+                    if (idx < span * parts) *(fo_u32x4*)(xs + (size_t)row * pitch + part * 16) = elu ? fo_elu8(v[u]) : v[u];
+                }
+            }
+            __syncthreads();
+            const int t = tblk + threadIdx.x;
+            if (t >= p.t0 + p.Lout) return;
+            float a0 = 0.f, a1 = 0.f;
+            for (int j = 0; j < p.J; ++j) {
+                const char* xr = xs + (size_t)(threadIdx.x * p.in_stride + j * p.tap_step) * pitch;
+                const fo_u32x4* wj = wpk + j * parts;
+                for (int c = 0; c < parts; ++c) {
+                    const fo_u32x4 xv = *(const fo_u32x4*)(xr + c * 16), wv = wj[c];
+                    a0 = fo_dot2(xv.x, wv.x, a0);
+                    a1 = fo_dot2(xv.y, wv.y, a1);
+                    a0 = fo_dot2(xv.z, wv.z, a0);
+                    a1 = fo_dot2(xv.w, wv.w, a1);
+                }
+            }
+            const int orow = t * p.out_stride + phase;
+            if (orow < 0 || orow >= p.LoutTot) return;
+            const size_t idx = ((size_t)b * p.LoutTot + orow);
+            float v = a0 + a1;
+            if (p.bias) v += p.bias[0];
+            v = act_apply(p.post_act, v);
+            if (p.dact_mode) v *= dact_apply(p.dact_mode, (float)((const T*)p.dact_src)[idx]);
+            if (p.res) v += (float)((const T*)p.res)[idx];
+            if (p.out_f32) { ((float*)p.y)[idx] = v; return; }
+            if (p.accumulate) v += (float)((T*)p.y)[idx];
+            ((T*)p.y)[idx] = (T)v;
+            return;
+        }
+    }
+    for (int i = threadIdx.x; i < p.M * KC; i += 256) wsm[i] = (float)w[i];
     for (int idx = threadIdx.x; idx < span * parts; idx += 256) {
         const int row = idx / parts, part = idx - row * parts;
         int R = R0 + row;
