@@ -270,7 +270,7 @@ static int stream_side(const ConvParams& p) {
 // single-channel form: 1 <= J <= 32 taps one sample apart, and every 8-sample piece any lane touches inside its item
 static int stream_cin1_ok(const ConvParams& p) {
     if (p.Cin != 1 || p.tap_step != 1 || p.J < 1 || p.J > 32 || p.in_stride < 1 || p.t0 != 0 || p.pad_mode != 0) return 0;
-    if (p.pre_act != GA_ACT_NONE || p.res || p.dact_mode || p.dact_src) return 0;
+    if (p.pre_act != GA_ACT_NONE || p.res) return 0;  // (a derivative source is fine: the decoder's last conv's data gradient)
     const int ks = (p.J + 15) / 16;
     if (p.off0 < 0 || (long)(p.Lout - 1) * p.in_stride + p.off0 + ks * 16 > p.Lin) return 0;
     return 1;
@@ -327,7 +327,8 @@ static int launch_stream_cin1(const ConvParams& p, hipStream_t s) {
     if (ng <= 0) return GA_OK;
     int grid = (ng + 3) / 4;
     if (grid > 2048) grid = 2048;
-    conv_stream_kernel<MT, KS, NT, false, SIDE_NONE, true><<<grid, 256, 0, s>>>(p, Ntot, ng, 1.0f / (float)p.Lout);
+    if (stream_side(p) == SIDE_DACT) conv_stream_kernel<MT, KS, NT, false, SIDE_DACT, true><<<grid, 256, 0, s>>>(p, Ntot, ng, 1.0f / (float)p.Lout);
+    else conv_stream_kernel<MT, KS, NT, false, SIDE_NONE, true><<<grid, 256, 0, s>>>(p, Ntot, ng, 1.0f / (float)p.Lout);
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -268,7 +268,14 @@ def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dac
         p.res_mode, p.res_coef, p.res_coef_dev = L.RES_FM_SIGN, float(fm_coef[0]), fm_coef[1].data_ptr()
     dx = torch.empty((B, lin, g.cin), device=gy.device, dtype=gy.dtype)
     alg = 2.0 * B * g.out_len(lin) * g.cout * g.cin * g.k if (g.kind == "conv" and g.stride > 1) else None
-    _launch_conv(p, gy, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL, alg_flops=alg)
+    gy_in = gy
+    if (CIN1_MFMA and g.kind == "cconv" and g.cout == 1 and g.dilation == 1 and g.k <= 15 and g.cin % 16 == 0 and g.cin <= 64
+            and gy.dtype == torch.bfloat16 and res is None and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA)):
+        # single-channel gradient (the decoder's last conv): the streaming MFMA kernel reads 8 consecutive samples per piece, so
+        # the windows that run past the end of an item need real zeros behind it (a copy of B*lin samples)
+        gy_in = torch.nn.functional.pad(gy, (0, 0, 0, _CIN1_BACK))
+        p.Lin = gy_in.shape[1]
+    _launch_conv(p, gy_in, wp_d, dx, res=res, dact_src=dact_src, impl=_IMPL, alg_flops=alg)
     if g.kind == "cconv" and g.k > 1:
         # fold the gradient of the reflected left pad back: dx[l] += dxp[-l], l = 1..P   (in_stride = -1)
         P = min((g.k - 1) * g.dilation, lin - 1)
