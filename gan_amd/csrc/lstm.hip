@@ -122,8 +122,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(ga_lstm_params p, in
                 const size_t hi = ((size_t)b * p.T + t) * H + u;
                 hout[hi] = (WT)h;
                 if (gsave && (p.B_save <= 0 || b < p.B_save)) {
-                    float* gs = gsave + ((size_t)b * p.T + t) * 4 * H + u;
-                    gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+                    *(float4*)(gsave + (((size_t)b * p.T + t) * H + u) * 4) = make_float4(ig, fg, gg, og);
                     csave[hi] = c;
                 }
                 if (layer == 1) ((AT*)p.y)[hi] = (AT)(h + (float)((const AT*)p.x_in)[hi]);
@@ -177,8 +176,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(ga_lstm_bwd_params p
                 float dh = red[0][uu][bb] + red[1][uu][bb] + red[2][uu][bb] + red[3][uu][bb];
                 const size_t hi = ((size_t)b * p.T + t) * H + u;
                 if (layer == 0) dh += (float)((const AT*)p.dy)[hi];
-                const float* gs = gates + ((size_t)b * p.T + t) * 4 * H + u;
-                const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
+                const float4 gs = *(const float4*)(gates + (((size_t)b * p.T + t) * H + u) * 4);
+                const float ig = gs.x, fg = gs.y, gg = gs.z, og = gs.w;
                 const float c = cs[hi];
                 const float cprev = t > 0 ? cs[hi - H] : 0.f;
                 const float tc = tanhf(c);
@@ -342,8 +341,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_fast_kernel(ga_lstm_params p
         const size_t hi = ((size_t)e_b * p.T + t) * H + e_u;
         hout[hi] = (WT)h;
         if (gsave && (p.B_save <= 0 || e_b < p.B_save)) {
-            float* gs = gsave + ((size_t)e_b * p.T + t) * 4 * H + e_u;
-            gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+            *(float4*)(gsave + (((size_t)e_b * p.T + t) * H + e_u) * 4) = make_float4(ig, fg, gg, og);
             csave[hi] = c;
         }
         if (layer == 1) ((AT*)p.y)[hi] = (AT)(h + x_skip);
@@ -380,8 +378,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_fast_kernel(ga_lstm_bwd_para
         const int b = b_base + i * 16 + e_bb;
         const int bl = b < p.B ? b : p.B - 1;
         const size_t hi = ((size_t)bl * p.T + t) * H + e_u;
-        const float* gs = gates + ((size_t)bl * p.T + t) * 4 * H + e_u;
-        e_ig[i] = gs[0]; e_fg[i] = gs[H]; e_gg[i] = gs[2 * H]; e_og[i] = gs[3 * H];
+        const float4 gs = *(const float4*)(gates + (((size_t)bl * p.T + t) * H + e_u) * 4);
+        e_ig[i] = gs.x; e_fg[i] = gs.y; e_gg[i] = gs.z; e_og[i] = gs.w;
         e_c[i] = cs[hi];
         e_cp[i] = cs[t > 0 ? hi - H : hi];
         e_dc[i] = dcs[(size_t)bl * H + e_u];

@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const size_t hi = ((size_t)b * T + c_t) * H + c_u;
                 float* gsave = c_layer == 0 ? p.gates1 : p.gates2;
                 if (gsave && (p.B_save <= 0 || b < p.B_save)) {
-                    float* gs = gsave + ((size_t)b * T + c_t) * 4 * H + c_u;
-                    gs[0] = o_i[i]; gs[H] = o_f[i]; gs[2 * H] = o_g[i]; gs[3 * H] = o_o[i];
+                    *(float4*)(gsave + (((size_t)b * T + c_t) * H + c_u) * 4) = make_float4(o_i[i], o_f[i], o_g[i], o_o[i]);  // one 16-byte store
                     (c_layer == 0 ? p.cs1 : p.cs2)[hi] = o_c[i];
                 }
                 if (c_layer == 1) y[hi] = (bf16_t)(o_h[i] + (float)e_in[i][0]);
@@ -419,8 +418,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int bl = b < p.B ? b : p.B - 1;
             const int tl = c_live ? c_t : 0;
             const size_t hi = ((size_t)bl * T + tl) * H + c_u;
-            const float* gs = gates + ((size_t)bl * T + tl) * 4 * H + c_u;
-            e_ig[i] = gs[0]; e_fg[i] = gs[H]; e_gg[i] = gs[2 * H]; e_og[i] = gs[3 * H];
+            const float4 gs = *(const float4*)(gates + (((size_t)bl * T + tl) * H + c_u) * 4);
+            e_ig[i] = gs.x; e_fg[i] = gs.y; e_gg[i] = gs.z; e_og[i] = gs.w;
             e_c[i] = cs[hi];
             e_cp[i] = cs[tl > 0 ? hi - H : hi];
             e_dy[i] = dy[hi];

@@ -338,7 +338,7 @@ typedef struct ga_lstm_params {
     void* y;          /* [B][T][H] act dtype */
     void* h1; void* h2; /* [B][T][H] w dtype: hidden-state history of the two layers */
     float* c1; float* c2; /* [B][H] */
-    float* gates1; float* gates2; /* [B][T][4H] or NULL */
+    float* gates1; float* gates2; /* [B][T][H][4] (i, f, g, o of a unit side by side: one 16-byte access) or NULL */
     float* cs1; float* cs2;       /* [B][T][H] or NULL */
     int B, T, H, act_dtype, w_dtype;
     int B_save; /* gates / cell states are recorded for batch items [0, B_save) only; <= 0 means all B */

@@ -18,3 +18,13 @@ for B in (16, 64, 128, 192, 256):
     xg = x.clone().requires_grad_(True)
     ta = t(lambda: ops.LstmSkip.apply(xg, w, B))
     print(f"B={B}: fwd no-grad {tn:.3f} ms ({tn/376*1e3:.2f} us/step)   saving all gates {ta:.3f} ms ({ta/376*1e3:.2f} us/step)", flush=True)
+# the step's shape: 256 items, the first 64 need gradients; and its backward
+x = torch.randn(256, 375, 512, device="cuda").bfloat16().requires_grad_(True)
+tm = t(lambda: ops.LstmSkip.apply(x, w, 64))
+y = ops.LstmSkip.apply(x, w, 64)
+gy = torch.randn_like(y)
+def fb():
+    y = ops.LstmSkip.apply(x, w, 64)
+    torch.autograd.grad(y, x, gy)
+tfb = t(fb)
+print(f"B=256 / 64 saved: fwd {tm:.3f} ms ({tm/376*1e3:.2f} us/step)   fwd+bwd {tfb:.3f} ms (bwd {(tfb-tm)/376*1e3:.2f} us/step)", flush=True)
