@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "libgan_amd.so"
 GA_MAX_PHASE = 8
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_ELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3, 4
-DACT_NONE, DACT_LRELU_FROM_OUT, DACT_ELU_FROM_IN = 0, 1, 2
+DACT_NONE, DACT_LRELU_FROM_OUT, DACT_ELU_FROM_IN, DACT_ELU_FROM_OUT = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_WINDOW, IMPL_MFMA_PP, IMPL_MFMA_LDSWIN = 0, 1, 2, 3, 4, 5
 IMPL_MFMA_STREAM, IMPL_MFMA_STREAMWIN = 6, 7
 KERNEL_GEMM_64x256, KERNEL_GEMM_128x128, KERNEL_GEMM_32x256 = 7, 8, 9
@@ -58,7 +58,7 @@ class WFinishItem(C.Structure):
 
 WFINISH_MAX_ROW = 15360
 PACK_CONV_FWD = 0
-RES_ADD, RES_FM_SIGN = 0, 1
+RES_ADD, RES_FM_SIGN, RES_ADD_THEN_ACT = 0, 1, 2
 PACK_MULTI_MAX = 24
 PACK_CONV_DGRAD_STRIDED = 2
 

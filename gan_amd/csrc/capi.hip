@@ -53,6 +53,8 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     // single-output-channel thin layers, long launches: the streaming-window kernel's dot-product form
     if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && p.res_mode == GA_RES_ADD && ga_conv_swin_wanted(p))
         return ga_conv_swin_impl(p, s);
+    if (p.res_mode == GA_RES_ADD_THEN_ACT)  // activation after the residual sum: the gathered-GEMM kernel's epilogue only
+        return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && p.res && p.ksplit <= 1) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
     if (p.res_mode != GA_RES_ADD) {  // only the gathered-GEMM kernel's epilogue forms the feature-matching term
         if (p.res_mode != GA_RES_FM_SIGN || !p.res || !p.dact_src || !p.dact_mode || !p.res_coef_dev) return GA_ERR_ARG;
         return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA)) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;

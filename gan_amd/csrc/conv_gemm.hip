@@ -306,6 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
     const bool simple_act = p.post_act == GA_ACT_NONE || p.post_act == GA_ACT_LRELU;
     const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
     const float fm_c = (p.res_mode == GA_RES_FM_SIGN && ksplit == 1) ? p.res_coef * p.res_coef_dev[0] : 0.f;
+    const bool fast_elu = p.post_act == GA_ACT_ELU && !p.out_f32;  // (bf16 output)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -336,12 +337,19 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
                 *(float4*)(wo + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 continue;
             }
-            if (simple_act) {  // none / LeakyReLU: one multiply-select per element
+            const bool act_after = p.res_mode == GA_RES_ADD_THEN_ACT;  // post_act(acc + bias + res)
+            if (act_after) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bv[i];
+            } else if (simple_act) {  // none / LeakyReLU: one multiply-select per element
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] += bv[i];
                     v[i] = v[i] > 0.f ? v[i] : slope * v[i];
                 }
+            } else if (fast_elu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = elu_bf16_grade(v[i] + bv[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = act_apply(p.post_act, v[i] + bv[i]);
@@ -364,6 +372,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
                     const bf16x8 d = *(const bf16x8*)(res + o);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += (float)d[i];
+                }
+                if (act_after) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fast_elu ? elu_bf16_grade(v[i]) : act_apply(p.post_act, v[i]);
                 }
             }
             if (p.accumulate) {
@@ -581,6 +593,7 @@ int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
+    if (p.res_mode == GA_RES_ADD_THEN_ACT && (!p.res || p.ksplit > 1 || p.dact_mode)) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
     if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
     if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)

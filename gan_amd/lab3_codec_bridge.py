@@ -85,6 +85,7 @@ class SeanetDecoder(nn.Module):
         self.precision = precision
         self.use_library_lstm = False  # True: torch's LSTM op (MIOpen) instead of the gan_amd step kernels (A/B checks)
         self.fuse_resblock = os.environ.get("GA_FUSE_RESBLOCK", "1") != "0"  # False: a residual unit as three autograd nodes (A/B checks)
+        self.fuse_elu = os.environ.get("GA_FUSE_ELU", "1") != "0"            # False: every ELU in front of a wide conv is a pass of its own
         self.ratios = tuple(int(r) for r in ratios)
         c = (2 ** len(self.ratios)) * num_filters
         layers = nn.Module()
@@ -163,7 +164,8 @@ class SeanetDecoder(nn.Module):
         return self._tail(h, dtype, self._plan)
 
     def _tail(self, h: torch.Tensor, dtype, plan) -> torch.Tensor:
-        for kind, name in plan:
+        elu_done = False  # h holds ELU(h): written by the residual unit in front (ops.ResBlockFrozen, elu_out)
+        for pos, (kind, name) in enumerate(plan):
             layer = getattr(self.layers, name)
             if kind == "conv":
                 h = self._conv(name, layer, h, dtype)
@@ -181,14 +183,22 @@ class SeanetDecoder(nn.Module):
                         self._packs[key] = ops.prepare_lstm_weights(layer.lstm, dtype)
                     h = ops.LstmSkip.apply(h, self._packs[key])
             elif kind == "elu_convt":
-                h = self._conv(name, layer, h, dtype, pre_act=L.ACT_ELU)
+                h = self._conv(name, layer, h, dtype, pre_act=ops.ACT_ELU_DONE if elu_done else L.ACT_ELU)
+                elu_done = False
             elif kind == "resblock":
                 b1, b3 = getattr(layer.block, "1"), getattr(layer.block, "3")
                 if h.dtype == torch.bfloat16 and self.fuse_resblock:  # one autograd node: no gradient-sum pass over h
+                    # where the conv behind an ELU would need a pass to materialise it (wide layers on the gathered-GEMM kernel),
+                    # the producing epilogue writes the ELU instead: inside the unit, and for the transposed conv that follows it
+                    nxt = plan[pos + 1] if pos + 1 < len(plan) else None
+                    elu_mid = self.fuse_elu and ops.elu_needs_a_pass(b3.geom, torch.empty((h.shape[0], h.shape[1], b3.geom.cin), dtype=h.dtype, device="meta"))
+                    elu_out = (self.fuse_elu and nxt is not None and nxt[0] == "elu_convt" and b3.geom.cout >= 128
+                               and ops.elu_needs_a_pass(getattr(self.layers, nxt[1]).geom, h))
                     h = ops.ResBlockFrozen.apply(
                         h, *self._pack(name + ".sc", layer.shortcut, dtype), layer.shortcut.conv.bias.data, layer.shortcut.geom,
                         *self._pack(name + ".b1", b1, dtype), b1.conv.bias.data, b1.geom,
-                        *self._pack(name + ".b3", b3, dtype), b3.conv.bias.data, b3.geom)
+                        *self._pack(name + ".b3", b3, dtype), b3.conv.bias.data, b3.geom, elu_mid, elu_out)
+                    elu_done = elu_out
                 else:
                     sc = self._conv(name + ".sc", layer.shortcut, h, dtype)
                     t = self._conv(name + ".b1", b1, h, dtype, pre_act=L.ACT_ELU)

@@ -241,11 +241,15 @@ def _cin1_padded(g: ConvGeom, x: Tensor):
 
 
 def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None,
-                 out_f32: bool = False) -> Tensor:
+                 out_f32: bool = False, act_after_res: bool = False) -> Tensor:
+    """act_after_res: y = post_act(conv + bias + res) instead of post_act(conv + bias) + res (GA_RES_ADD_THEN_ACT)."""
     B, lin, cin = x.shape
     assert cin == g.cin, (cin, g.cin)
     p = fwd_params(g, B, lin)
     p.pre_act, p.post_act = pre_act, post_act
+    if act_after_res:
+        assert res is not None and x.dtype == torch.bfloat16
+        p.res_mode = L.RES_ADD_THEN_ACT
     p.out_f32 = 1 if (out_f32 and x.dtype == torch.bfloat16) else 0
     y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=torch.float32 if p.out_f32 else x.dtype)
     if not pre_act and res is None and not p.out_f32:
@@ -840,27 +844,50 @@ def _streams_with_pre_act(g: ConvGeom, x: Tensor, pre_act: int) -> bool:
     return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) in (L.KERNEL_STREAM, L.KERNEL_STREAM_WIN)
 
 
-def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int, res=None, out_f32: bool = False) -> Tensor:
-    if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and not _streams_with_pre_act(geom, x, pre_act):
+def elu_needs_a_pass(g: ConvGeom, x: Tensor) -> bool:
+    """True when conv(ELU(x)) of frozen layer g would materialise ELU(x) with a pass of its own (bf16 layers that run on the
+    gathered-GEMM kernel): the producer of x can then emit ELU(x) itself (ACT_ELU_DONE below)."""
+    return x.dtype == torch.bfloat16 and g.cout >= 16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) and not _streams_with_pre_act(g, x, L.ACT_ELU)
+
+
+# pre_act code of ConvFrozen / _frozen_forward: the input tensor already holds ELU(pre-activation) -- written by its producer's
+# epilogue -- so the forward applies nothing and the data gradient takes ELU' from that output (GA_DACT_ELU_FROM_OUT)
+ACT_ELU_DONE = -2
+
+
+def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int, res=None, out_f32: bool = False, post_act: int = 0,
+                    act_after_res: bool = False) -> Tensor:
+    res = None if res is None else res.contiguous()
+    if pre_act == ACT_ELU_DONE:
+        pre_act = L.ACT_NONE
+    if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and (post_act or not _streams_with_pre_act(geom, x, pre_act)):
         # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
         # which cannot transform its operand in flight (the thin layers' streaming kernels can: no copy there)
-        return conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, res=None if res is None else res.contiguous(), out_f32=out_f32)
-    return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, res=None if res is None else res.contiguous(), out_f32=out_f32)
+        return conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res)
+    return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res)
 
 
 class ResBlockFrozen(torch.autograd.Function):
     """SEANet residual unit with frozen weights (HF modeling_encodec.py:320-343: shortcut(x) + conv_k1(ELU(conv_k(ELU(x))))) as ONE
     autograd node.  As three ConvFrozen nodes, autograd sums the two gradients that reach x (shortcut and block) with an
     element-wise pass over the unit's input -- the largest activations of the step; here the shortcut's data-gradient launch
-    takes the block's gradient as its residual operand and adds it in its epilogue."""
+    takes the block's gradient as its residual operand and adds it in its epilogue.
+
+    elu_mid: the first conv's epilogue writes ELU(t) instead of t (t is used through ELU only), so the second conv needs no
+    ELU pass over its input; its data gradient takes ELU'(t) from that output (GA_DACT_ELU_FROM_OUT).
+    elu_out: the unit's output y is consumed through ELU only (by the transposed conv behind it): the second conv's epilogue
+    writes ELU(conv + bias + shortcut) (GA_RES_ADD_THEN_ACT).  The node then RETURNS ELU(y) and EXPECTS dL/dy as its incoming
+    gradient: its consumer must be a ConvFrozen with pre_act = ACT_ELU_DONE, whose data gradient applies ELU'(y) itself."""
 
     @staticmethod
-    def forward(ctx, x, sc_f, sc_d, sc_b, g_sc: ConvGeom, b1_f, b1_d, b1_b, g1: ConvGeom, b3_f, b3_d, b3_b, g3: ConvGeom):
+    def forward(ctx, x, sc_f, sc_d, sc_b, g_sc: ConvGeom, b1_f, b1_d, b1_b, g1: ConvGeom, b3_f, b3_d, b3_b, g3: ConvGeom,
+                elu_mid: bool = False, elu_out: bool = False):
         x = x.contiguous()
         sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
-        t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU)
-        y = _frozen_forward(g3, t, b3_f, b3_b, L.ACT_ELU, res=sc)
-        ctx.geoms = (g_sc, g1, g3)
+        t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
+        y = _frozen_forward(g3, t, b3_f, b3_b, ACT_ELU_DONE if elu_mid else L.ACT_ELU, res=sc,
+                            post_act=L.ACT_ELU if elu_out else L.ACT_NONE, act_after_res=elu_out)
+        ctx.geoms, ctx.elu_mid = (g_sc, g1, g3), elu_mid
         ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
         return y
 
@@ -871,10 +898,10 @@ class ResBlockFrozen(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous().to(x.dtype)
-            gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=t)
+            gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_OUT if ctx.elu_mid else L.DACT_ELU_FROM_IN, dact_src=t)
             gb = conv_dgrad(g1, gt, b1_d, x.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
             gx = conv_dgrad(g_sc, gy, sc_d, x.shape[1], res=gb)
-        return (gx,) + (None,) * 12
+        return (gx,) + (None,) * 14
 
 
 class ConvFrozen(torch.autograd.Function):
@@ -897,7 +924,9 @@ class ConvFrozen(torch.autograd.Function):
         gy = gy.contiguous().to(ctx.x_dtype)
         gx = None
         if ctx.needs_input_grad[0]:
-            if ctx.pre_act == L.ACT_ELU:
+            if ctx.pre_act == ACT_ELU_DONE:  # x holds ELU(pre-activation): the returned gradient is w.r.t. the pre-activation
+                gx = conv_dgrad(ctx.geom, gy, wp_d, ctx.lin, dact_mode=L.DACT_ELU_FROM_OUT, dact_src=x)
+            elif ctx.pre_act == L.ACT_ELU:
                 gx = conv_dgrad(ctx.geom, gy, wp_d, ctx.lin, dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
             elif ctx.pre_act == L.ACT_NONE:
                 gx = conv_dgrad(ctx.geom, gy, wp_d, ctx.lin)

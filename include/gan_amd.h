@@ -45,6 +45,7 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 #define GA_DACT_NONE 0
 #define GA_DACT_LRELU_FROM_OUT 1
 #define GA_DACT_ELU_FROM_IN 2
+#define GA_DACT_ELU_FROM_OUT 3 /* dact_src holds u = ELU(pre-activation): factor 1 for u > 0, else u + 1 (= exp of the pre-activation) */
 
 #define GA_IMPL_AUTO 0   /* MFMA for bf16 when the shape fills tiles, else direct */
 #define GA_IMPL_DIRECT 1 /* vector-ALU fp32 FMA chains (exact fp32 mode, thin layers) */
@@ -98,12 +99,16 @@ typedef struct ga_conv_params {
     int res_mode;   /* GA_RES_ADD (0): epi adds res.  GA_RES_FM_SIGN (MFMA GEMM kernel only; needs dact_mode, dact_src, res
                     and res_coef_dev): res holds the REAL feature map that pairs with the fake one in dact_src, and epi adds
                     res_coef * res_coef_dev[0] * sign(dact_src - res) * dact(dact_src) -- the feature-matching L1 gradient
-                    (lab3_codec_models.py:191-199) formed in the data-gradient epilogue instead of in two passes of its own */
+                    (lab3_codec_models.py:191-199) formed in the data-gradient epilogue instead of in two passes of its own.
+                    GA_RES_ADD_THEN_ACT (MFMA GEMM kernel only, needs res, no split-K): y = post_act(acc + bias + res) -- the
+                    activation AFTER the residual sum, so that a SEANet residual unit can hand ELU(unit output) straight to
+                    the transposed conv behind it (modeling_encodec.py:340-343 then :268) with no pass of its own */
     float res_coef;
     const float* res_coef_dev; /* device scalar (the loss term's upstream gradient) */
 } ga_conv_params;
 #define GA_RES_ADD 0
 #define GA_RES_FM_SIGN 1
+#define GA_RES_ADD_THEN_ACT 2
 
 /* replaces: F.conv1d / F.conv_transpose1d forward and their input gradients
  *   G   lab3_codec_models.py:31-32,75,86 (k3, dilation 1/2/4/8)
