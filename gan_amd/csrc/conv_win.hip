@@ -12,8 +12,8 @@
 //   Cin = 64 (S = 1, J <= 12: D blocks.1 data gradient with its four output phases folded into 128 channels)
 //                                                        tile 128 (m) x 128 (n), 4 waves as 2 x 2, wave tile 64 x 64
 //   K-step 64 = 2 taps x 32 channels or 1 tap x 64 channels; weights [BM][64] per step, 128-byte rows, XOR-swizzled as in
-//   conv_gemm.hip; window 35 KiB / 18 KiB + 24 / 48 KiB of weight ring: two workgroups per CU, so one workgroup's window fill
-//   hides behind the other's multiply.
+//   conv_gemm.hip; window 35 KiB / 18 KiB + a weight ring of two stages (16 / 32 KiB): three workgroups per CU, so one
+//   workgroup's window fill hides behind the others' multiply (a three-stage ring, two workgroups per CU, is 15-20 % slower).
 //   Window image: row r of the window sits at its natural byte offset r*2*Cin, except that inside every aligned 256-byte line
 //   (4 rows of 64 B or 2 rows of 128 B = 16 sixteen-byte slots) slot s is stored at s ^ (line & 15).  A B fragment reads 32
 //   rows S*2*Cin bytes apart at one channel slot: without the XOR those are 16 reads of the same bank quarter per 16-lane group,
@@ -37,8 +37,8 @@ __device__ __forceinline__ uintptr_t cw_sel(bool ok, uintptr_t a, uintptr_t z) {
 
 #define CW_BN 128
 
-template <int CIN, int S, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvParams p, int tiles_per_item, int total, int Ktot, int nsteps) {
+template <int CIN, int S, int WM, int WN, int RING>
+__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void conv_win_kernel(ConvParams p, int tiles_per_item, int total, int Ktot, int nsteps) {
     constexpr int MI = 2;                        // 32-row MFMA tiles per wave along m
     constexpr int NI = CW_BN / (WN * 32);        // along n
     constexpr int BM = WM * MI * 32;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvParams p, int tile
     static_assert(WM * WN == 4, "four waves");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const Wl = smem;                       // window
-    char* const Al = smem + WBYTES;              // [3][BM][128 B]
+    char* const Al = smem + WBYTES;              // [RING][BM][128 B]
 
     const int id = blockIdx.x;
     const int chunk = (total + 7) / 8;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvParams p, int tile
             cw_glds16(cw_sel(kin && abase[i], abase[i] + (uintptr_t)step * 128, zero), dst + i * 4096);
     };
     issue_A(0, 0);
-    issue_A(1, 1);
+    if (RING == 3) issue_A(1, 1);
 
     const int m0_ = mbase + wm * (MI * 32) + (lane % (MI * 4)) * 8;
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -132,13 +132,14 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvParams p, int tile
 
     for (int ks = 0; ks < nsteps; ++ks) {
         // stage ks has landed (and, at ks == 0, the window): all but the newest stage's loads are retired
-        if (ks + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+        if (RING == 3 && ks + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + 2 < nsteps) issue_A(ks + 2, (ks + 2) % 3);  // the buffer stage ks-1 was read from (everyone is past that read)
-        const char* Ab = Al + (ks % 3) * ABYTES + aoff;
+        // refill the buffer stage ks-1 was read from (everyone is past that read)
+        if (ks + RING - 1 < nsteps) issue_A(ks + RING - 1, (ks + RING - 1) % RING);
+        const char* Ab = Al + (ks % RING) * ABYTES + aoff;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int tap = CIN == 32 ? (kk >> 1) : 0;
@@ -257,7 +258,7 @@ int ga_conv_win_wanted(const ConvParams& p) {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("GA_CONV_WIN");
-        mode = e ? atoi(e) : 1;
+        mode = e ? atoi(e) : 2;
     }
     if (!mode) return 0;
     const int kind = ga_conv_win_supported(p);
@@ -265,13 +266,13 @@ int ga_conv_win_wanted(const ConvParams& p) {
     if (p.J * p.Cin < 512 || p.Lout < 2 * CW_BN) return 0;            // short K / short items: the gathered kernel's ground
     const long tiles = (long)p.B * ((p.Lout + CW_BN - 1) / CW_BN) * ((p.M + (kind == 1 ? 63 : 127)) / (kind == 1 ? 64 : 128));
     if (tiles < 1024) return 0;                                        // two workgroups per CU, a few rounds
-    // measured at B = 128 (scratch/win_check.py): the stride-4 form is 25-28 % faster than the gathered kernel (514 -> 656-700
-    // TFLOP/s on D blocks.1 forward); the stride-1 form only ties it (its epilogue's mask read and 128-channel rows dominate), so
-    // it runs on request only (GA_CONV_WIN=2 or GA_IMPL_MFMA_LDSWIN)
+    // measured at B = 128 (scratch/win_check.py), two-stage weight ring: the stride-4 form 788-840 TFLOP/s against 514-550 for the
+    // gathered kernel on D blocks.1 forward; the stride-1 form 625-630 against 520-540 on its folded data gradient (with the
+    // three-stage ring, two workgroups per CU, it only tied).  GA_CONV_WIN=1 keeps the stride-1 form off, 0 both.
     return (kind == 1 || mode >= 2) ? kind : 0;
 }
 
-template <int CIN, int S, int WM, int WN>
+template <int CIN, int S, int WM, int WN, int RING>
 static int launch_win(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * 64;
     constexpr int JMAX = CIN == 32 ? 44 : 12;
@@ -283,10 +284,10 @@ static int launch_win(const ConvParams& p, hipStream_t s) {
     const long total = (long)p.B * tpi * ((p.M + BM - 1) / BM);
     if (total <= 0) return GA_OK;
     if (total > (1L << 30)) return GA_ERR_ARG;
-    size_t lds = WBYTES + 3 * BM * 128;
+    size_t lds = WBYTES + RING * BM * 128;
     const size_t epi = 4 * 32 * (64 + 4) * sizeof(float);
     if (lds < epi) lds = epi;
-    auto kern = conv_win_kernel<CIN, S, WM, WN>;
+    auto kern = conv_win_kernel<CIN, S, WM, WN, RING>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GA_ERR_LAUNCH;
     const int grid = (int)((total + 7) / 8 * 8);
@@ -295,11 +296,22 @@ static int launch_win(const ConvParams& p, hipStream_t s) {
     return GA_OK;
 }
 
+static int win_ring() {
+    static int ring = -1;
+    if (ring < 0) {
+        const char* e = getenv("GA_CONV_WIN_RING");
+        ring = e ? atoi(e) : 2;
+    }
+    return ring;
+}
+
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s) {
     if (!p.x || !p.w || !p.y) return GA_ERR_ARG;
     switch (ga_conv_win_supported(p)) {
-        case 1: return launch_win<32, 4, 1, 4>(p, s);
-        case 2: return launch_win<64, 1, 2, 2>(p, s);
+        // weight ring of two stages (three workgroups per CU) or three (two per CU): GA_CONV_WIN_RING, default 2 -- measured at
+        // B = 128 on the stride-4 form: 667-700 -> 788-840 TFLOP/s; occupancy, not prefetch depth, was the limit
+        case 1: return win_ring() == 3 ? launch_win<32, 4, 1, 4, 3>(p, s) : launch_win<32, 4, 1, 4, 2>(p, s);
+        case 2: return win_ring() == 3 ? launch_win<64, 1, 2, 2, 3>(p, s) : launch_win<64, 1, 2, 2, 2>(p, s);
         default: return GA_ERR_ARG;
     }
 }
