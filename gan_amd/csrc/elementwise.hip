@@ -895,16 +895,36 @@ __global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, co
     constexpr int EV = 16 / sizeof(T);
     float s = 0.f;
     const size_t nv = vec ? n / EV : 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    // four pieces per operand and trip, all requested before the first is used (bytes in flight, not arithmetic, set the pace:
+    // with one piece per trip the feature-matching sums ran at 4 TB/s)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+        Pack16<T> av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = ((const Pack16<T>*)a)[i + u * stride];
+            if (b) bv[u] = ((const Pack16<T>*)b)[i + u * stride];
+        }
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            s += red_f(op, (float)av[0].v[e], b ? (float)bv[0].v[e] : 0.f);
+            s1 += red_f(op, (float)av[1].v[e], b ? (float)bv[1].v[e] : 0.f);
+            s2 += red_f(op, (float)av[2].v[e], b ? (float)bv[2].v[e] : 0.f);
+            s3 += red_f(op, (float)av[3].v[e], b ? (float)bv[3].v[e] : 0.f);
+        }
+    }
+    for (; i < nv; i += stride) {
         const Pack16<T> av = ((const Pack16<T>*)a)[i];
         Pack16<T> bv;
         if (b) bv = ((const Pack16<T>*)b)[i];
 #pragma unroll
         for (int e = 0; e < EV; ++e) s += red_f(op, (float)av.v[e], b ? (float)bv.v[e] : 0.f);
     }
-    for (size_t i = nv * EV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        s += red_f(op, (float)a[i], b ? (float)b[i] : 0.f);
-    s = block_sum(s, red);
+    for (size_t k = nv * EV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        s += red_f(op, (float)a[k], b ? (float)b[k] : 0.f);
+    s = block_sum((s + s1) + (s2 + s3), red);
     if (threadIdx.x == 0) atomicAdd(out, s * scale);
 }
 
@@ -989,12 +1009,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     float s = 0.f;
     const size_t n4 = n / 4;
     const float4* g4 = (const float4*)g;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four loads in flight per lane
+        const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+        s += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+        s1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        s2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+        s3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+    }
+    for (; i < n4; i += stride) {
         const float4 v = g4[i];
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i] * g[i];
-    s = block_sum(s, red);
+    for (size_t k = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) s += g[k] * g[k];
+    s = block_sum((s + s1) + (s2 + s3), red);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
