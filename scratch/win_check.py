@@ -13,8 +13,9 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 torch.manual_seed(0)
-g = ConvGeom("conv", 32, 64, 41, 4, 20, 1)
-for Ln in (S, S // 2, S // 4, 3001):
+blk = sys.argv[2] if len(sys.argv) > 2 else "b1"
+g = ConvGeom("conv", 32, 64, 41, 4, 20, 1) if blk == "b1" else ConvGeom("conv", 64, 128, 41, 4, 20, 1)
+for Ln in ((S, S // 2, S // 4, 3001) if blk == "b1" else (S // 4, S // 8, S // 16)):
     x = torch.randn(B, Ln, g.cin, device="cuda").bfloat16()
     w = torch.randn(*g.wdims, device="cuda") / (g.cin * g.k) ** 0.5
     bias = torch.randn(g.cout, device="cuda")
