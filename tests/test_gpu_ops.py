@@ -913,6 +913,57 @@ def test_streaming_window_kernel_matches_register_streaming_and_direct_kernels()
     assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM
 
 
+def test_single_output_window_kernel_and_last_conv_gradient_match_direct_kernels():
+    """conv_swin1_kernel (the window ring with four chains of 16x16x32 MFMAs per 64-step tile) on the two single-output layers it
+    takes -- the decoder's last conv (32 -> 1, k7, reflect-causal, ELU in front, fp32 out) and D blocks.0's data gradient
+    (32 -> 1, k15, zero padding both sides, bf16 out) -- against the fp32-accumulating direct kernel on the same bf16 operands;
+    ragged last tiles, items shorter than a tile, several tiles per wave.  And the last conv's data gradient (1 -> 32 channels,
+    ELU' from the layer input in the epilogue), which runs on the single-channel streaming kernel over a zero-padded copy."""
+    torch.manual_seed(36)
+    g_last = ConvGeom("cconv", 32, 1, 7)
+    g_d0 = ConvGeom("conv", 1, 32, 15, 1, 7, 1)
+    for B, Ln in ((3, 4099), (2, 50), (5, 66000)):
+        x = torch.randn(B, Ln, 32, device=DEV).bfloat16()
+        w = torch.randn(*g_last.wdims, device=DEV) / (32 * 7) ** 0.5
+        bias = torch.randn(1, device=DEV)
+        wf, wd = ops.pack_weight(g_last, w, g_last.fwd_pack, torch.bfloat16), ops.pack_weight(g_last, w, g_last.dgrad_pack, torch.bfloat16)
+        outs = {}
+        for name, impl in (("swin", L.IMPL_MFMA_STREAMWIN), ("direct", L.IMPL_DIRECT)):
+            ops.set_conv_impl(impl)
+            try:
+                outs[name] = ops.conv_forward(g_last, x, wf, bias, pre_act=L.ACT_ELU, out_f32=True).cpu()
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
+        close(outs["swin"], outs["direct"], 5e-3, f"last conv fwd B={B} L={Ln}")
+        gy = torch.randn(B, Ln, 1, device=DEV).bfloat16()
+        dx_auto = ops.conv_dgrad(g_last, gy, wd, Ln, dact_mode=L.DACT_ELU_FROM_IN, dact_src=x).float().cpu()
+        ops.set_conv_impl(L.IMPL_DIRECT)
+        try:
+            dx_dir = ops.conv_dgrad(g_last, gy, wd, Ln, dact_mode=L.DACT_ELU_FROM_IN, dact_src=x).float().cpu()
+        finally:
+            ops.set_conv_impl(L.IMPL_AUTO)
+        close(dx_auto, dx_dir, 1.5e-2, f"last conv dgrad B={B} L={Ln}")
+        w0 = torch.randn(*g_d0.wdims, device=DEV) / 15 ** 0.5
+        wd0 = ops.pack_weight(g_d0, w0, g_d0.dgrad_pack, torch.bfloat16)
+        g32 = torch.randn(B, Ln, 32, device=DEV).bfloat16()
+        outs = {}
+        for name, impl in (("swin", L.IMPL_MFMA_STREAMWIN), ("direct", L.IMPL_DIRECT)):
+            ops.set_conv_impl(impl)
+            try:
+                outs[name] = ops.conv_dgrad(g_d0, g32, wd0, Ln).float().cpu()
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
+        close(outs["swin"], outs["direct"], 1.5e-2, f"D blocks.0 dgrad B={B} L={Ln}")
+    # AUTO takes the window kernel for long launches of both
+    p = ops.fwd_params(g_last, 4, 120000)
+    p.x = p.w = p.y = 256
+    p.pre_act, p.out_f32 = L.ACT_ELU, 1
+    assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM_WIN
+    q = ops.dgrad_params(g_d0, 4, 120000)
+    q.x = q.w = q.y = 256
+    assert L.lib().ga_conv_kernel_id(C.byref(q), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM_WIN
+
+
 def test_fused_residual_unit_matches_three_node_form():
     """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
     block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
