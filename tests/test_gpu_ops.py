@@ -964,6 +964,30 @@ def test_single_output_window_kernel_and_last_conv_gradient_match_direct_kernels
     assert L.lib().ga_conv_kernel_id(C.byref(q), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM_WIN
 
 
+def test_activation_after_residual_and_elu_derivative_from_output():
+    """GA_RES_ADD_THEN_ACT (y = ELU(conv + bias + res), gathered-GEMM epilogue) and GA_DACT_ELU_FROM_OUT (the data gradient takes
+    ELU'(pre-activation) from u = ELU(pre-activation): 1 for u > 0, else u + 1) against torch on the CPU, bf16 bound."""
+    torch.manual_seed(37)
+    g = ConvGeom("cconv", 64, 128, 1)
+    B, Ln = 3, 700
+    x = torch.randn(B, Ln, 64, device=DEV).bfloat16()
+    res = torch.randn(B, Ln, 128, device=DEV).bfloat16()
+    w = torch.randn(*g.wdims, device=DEV) / 8.0
+    bias = torch.randn(128, device=DEV)
+    wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+    y = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_ELU, res=res, act_after_res=True).float().cpu()
+    wq = w.bfloat16().float().cpu()
+    pre = F.conv1d(x.float().cpu().permute(0, 2, 1), wq, bias.cpu()) + res.float().cpu().permute(0, 2, 1)
+    close(y, F.elu(pre).permute(0, 2, 1), TOL[torch.bfloat16], "ELU(conv + bias + res)")
+    # data gradient of conv(u) w.r.t. the pre-activation behind u = ELU(pre): dgrad(gy) * ELU'(pre), ELU' read off u
+    u = F.elu(torch.randn(B, Ln, 64, device=DEV)).bfloat16()
+    gy = torch.randn(B, Ln, 128, device=DEV).bfloat16()
+    dx = ops.conv_dgrad(g, gy, wd, Ln, dact_mode=L.DACT_ELU_FROM_OUT, dact_src=u).float().cpu()
+    uf = u.float().cpu()
+    want = F.conv_transpose1d(gy.float().cpu().permute(0, 2, 1), wq).permute(0, 2, 1) * torch.where(uf > 0, torch.ones_like(uf), uf + 1.0)
+    close(dx, want, TOL[torch.bfloat16], "dgrad * ELU'(from output)")
+
+
 def test_fused_residual_unit_matches_three_node_form():
     """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
     block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
