@@ -144,11 +144,25 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
     // stages walk the TAPS of one channel chunk first ("tap-fast"): consecutive stages then gather the same x rows shifted
     // by one tap, so the re-read comes a stage later and hits L2, instead of Cin/64 stages later behind everything the other
     // workgroups of the XCD have streamed through it meanwhile (PMC: 11-tap layers fetched their input 11 times over).
-    const bool tapfast = !(mgroup_flags & 0x10000) && p.J > 1 && Cin > GBK && Cin % GBK == 0;
-    int st_k, st_c, st_dR, st_kk, st_j = 0;
+    // Strided layers (the k41 stride-4 forward convs): tap j of output step n reads row S*n + j, so taps j and j + S read the SAME
+    // rows one step apart.  "Phase-fast": within a channel chunk the taps go phi, phi+S, phi+2S, ... for phi = 0 .. S-1, so that
+    // consecutive stages gather (all but one of) the rows of the stage before -- from L2 -- where plain tap order comes back to a
+    // row S stages later, after the XCD's other workgroups have pushed ~16 MB through its 4 MB L2 (PMC, per launch at B = 128:
+    // D blocks.4 forward fetched 1.45 GB from the fabric for 0.12 GB of input, blocks.2 / .3 the same ~10x).
+    const int TS = (mgroup_flags & 0x20000) && S > 1 && S <= 8 && p.tap_step == 1 && p.J > S ? S : 1;
+    const bool tapfast = !(mgroup_flags & 0x10000) && p.J > 1 && (TS > 1 ? Cin >= GBK : Cin > GBK) && Cin % GBK == 0;
+    int st_k, st_c, st_dR, st_kk, st_j = 0, st_phi = 0;
     if (tapfast) {
         int cc0;
         divmod_small(ks_begin, p.J, __builtin_amdgcn_rcpf((float)p.J), cc0, st_j);
+        if (TS > 1) {  // st_j is the position in the chunk's tap sequence: find its phase and tap
+            int t = st_j;
+            while (t >= (p.J - st_phi + TS - 1) / TS) {
+                t -= (p.J - st_phi + TS - 1) / TS;
+                ++st_phi;
+            }
+            st_j = st_phi + t * TS;
+        }
         st_c = cc0 * GBK + piece * 8;
         st_k = st_j * Cin + st_c;
         st_dR = st_j * p.tap_step;
@@ -186,6 +200,20 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
                 const bool ok = kin && xitem[i] && R < p.Lin;
                 glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * (NT * 16));
             }
+        }
+        if (tapfast && TS > 1) {
+            st_j += TS;
+            if (st_j >= p.J) {  // next phase; after the last one the next channel chunk
+                if (++st_phi == TS) {
+                    st_phi = 0;
+                    st_c += GBK;
+                }
+                st_j = st_phi;
+            }
+            st_k = st_j * Cin + st_c;
+            st_dR = st_j;  // (tap_step == 1)
+            st_kk = st_j * tapB + st_c * 2;
+            return;
         }
         if (tapfast) {
             st_k += Cin;
@@ -556,6 +584,8 @@ static int gemm_mgroup() {
         if (v < 1) v = 1;
         const char* t = getenv("GA_GEMM_TAPFAST");  // "0": keep the plain (tap, channel) K order
         if (t && t[0] == '0') v |= 0x10000;
+        const char* ph = getenv("GA_GEMM_PHASEFAST");  // "0": plain tap order on strided layers too
+        if (!(ph && ph[0] == '0')) v |= 0x20000;
     }
     return v;
 }
