@@ -151,7 +151,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
-    ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass instead of after it")
+    ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass (the default above one rank)")
+    ap.add_argument("--no-dp-overlap", action="store_true", help="all-reduce after the backward pass")
     args = ap.parse_args()
     # the contract is ONE line on stdout: libraries that print banners there (RCCL prints its version at init) go to stderr
     json_fd = os.dup(1)
@@ -174,7 +175,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         from gan_amd.dp import DataParallel
         dp = DataParallel()
-        dp.overlap = bool(args.dp_overlap)
+        if args.dp_overlap:
+            dp.overlap = True
+        elif args.no_dp_overlap:
+            dp.overlap = False  # (otherwise DataParallel's own default: overlapped above one rank)
 
     from gan_amd import ops
     from gan_amd.lab3_codec_models import CodecTrainWeights
@@ -237,10 +241,13 @@ def main():
     # convolution launch; achieved = launched multiply-add flops / event time, per kernel.
     roofline = None
     kernels = {}
+    # (every rank takes this step -- it contains the gradient all-reduces -- and rank 0 keeps the events)
     if rank == 0:
         ops.PROFILE = []
+    if rank == 0 or world > 1:
         step()
         torch.cuda.synchronize()
+    if rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         if args.conv_table:
             rows = {}
