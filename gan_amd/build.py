@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libgan_amd.so"
-SOURCES = ["capi.hip", "conv_direct.hip", "conv_mfma.hip", "conv_gemm.hip", "conv_pp.hip", "conv_win.hip", "conv_stream.hip", "conv_swin.hip", "wgrad_mfma.hip", "wgrad_gemm.hip", "wgrad_cin1_mfma.hip", "thin.hip", "lstm.hip", "lstm_persist.hip", "elementwise.hip", "stft.hip"]
+SOURCES = ["capi.hip", "conv_direct.hip", "conv_mfma.hip", "conv_gemm.hip", "conv_pp.hip", "conv_win.hip", "conv_stream.hip", "conv_swin.hip", "resunit.hip", "wgrad_mfma.hip", "wgrad_gemm.hip", "wgrad_cin1_mfma.hip", "thin.hip", "lstm.hip", "lstm_persist.hip", "elementwise.hip", "stft.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -23,7 +23,7 @@ def _stale(out: Path, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [CSRC / "common.h", HERE.parent / "include" / "gan_amd.h"]
+    headers = [CSRC / "common.h", CSRC / "swin_common.h", HERE.parent / "include" / "gan_amd.h"]
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     jobs = []

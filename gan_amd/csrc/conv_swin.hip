@@ -19,68 +19,8 @@
 //   * epilogue: bias and activation on the accumulators, bf16 rows through a wave-private LDS stage, 16-byte row-contiguous stores
 // The K order (tap-major, then channel), the accumulation chain and the rounding points are those of conv_stream_kernel:
 // results are bit-identical (scratch/swin_check.py, tests/test_gpu_ops.py).
-#include "common.h"
+#include "swin_common.h"
 #include <stdlib.h>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-typedef const __attribute__((address_space(1))) bf16x8* gfrag_ptr_t;
-typedef __attribute__((address_space(3))) char* lds_char_ptr_t;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void sw_glds16(uintptr_t src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ uintptr_t sw_sel(bool ok, uintptr_t a, uintptr_t z) {
-    return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
-}
-
-// LDS stores while direct-to-LDS loads are in flight: the compiler cannot tell that a ds_write and a pending LDS-DMA write do not
-// alias and puts s_waitcnt vmcnt(0) in front of every ds_write it emits itself (and in front of LDS reads through struct types:
-// the reads below go through vector types, which it lets pass), which would drain the prefetched tiles once per tile.  The
-// stores are therefore issued as asm: LDS executes one wave's instructions in order, so the plain reads that follow see them,
-// and the data registers are read at issue.
-__device__ __forceinline__ void sw_lds_write16(void* dst, u32x4 v) {
-    const unsigned a = (unsigned)(uintptr_t)(lds_char_ptr_t)dst;
-    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
-__device__ __forceinline__ void sw_lds_write8(void* dst, u32x2 v) {
-    const unsigned a = (unsigned)(uintptr_t)(lds_char_ptr_t)dst;
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
-
-__device__ __forceinline__ unsigned int sw_pack_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    union { bf16x2 b; unsigned int u; } pk;
-    pk.b[0] = (__bf16)lo;
-    pk.b[1] = (__bf16)hi;
-    return pk.u;
-}
-
-// ELU on eight bf16 (the arithmetic of conv_stream.hip's elu_frag: identical results), two elements per step so that the
-// multiply / add / convert are packed instructions; f > -2^-12 returns f itself (expm1(f) = f there to inside half a bf16 ulp)
-__device__ __forceinline__ u32x4 sw_elu8(u32x4 in) {
-    u32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x2 f;
-        f.x = __uint_as_float(in[i] << 16);
-        f.y = __uint_as_float(in[i] & 0xffff0000u);
-        const f32x2 t = f * 1.4426950408889634f;
-        f32x2 e;
-        e.x = __builtin_amdgcn_exp2f(t.x);
-        e.y = __builtin_amdgcn_exp2f(t.y);
-        e = e - 1.0f;
-        const float rx = f.x > -2.44140625e-4f ? f.x : e.x;
-        const float ry = f.y > -2.44140625e-4f ? f.y : e.y;
-        out[i] = sw_pack_bf16(rx, ry);
-    }
-    return out;
-}
 
 template <int CIN, int J, int MT, int NT, int RD, int WPB>
 struct SwinCfg {

@@ -1,0 +1,267 @@
+// One SEANet residual unit of the frozen decoder as ONE pass over its input (gfx950, bf16):
+//     y = W_sc x + b_sc + W3 ELU(W1 * ELU(x) + b1) + b3         (HF modeling_encodec.py:320-343; C -> C/2 -> C, causal k3)
+// for the thin end of the decoder (C = 32 at 120000 steps per item, C = 64 at 60000).  As three ga_conv launches the unit reads
+// x twice, writes and reads the shortcut and the hidden tensor, and writes y: 4.5 C-wide passes for 2; every launch is HBM-bound
+// (conv_stream.hip / conv_swin.hip), so the unit's time is its bytes.  Here, per wave (the ring of conv_swin.hip: windows of
+// NR + 2 input rows go global -> LDS with global_load_lds_dwordx4 one tile ahead, private to the wave, no workgroup barrier in
+// the loop, one counted vmcnt per tile):
+//   1. shortcut: W_sc x on the RAW window (the B fragments of the k3 conv's last tap, before the ELU) into the accumulators
+//      that the unit's output is summed in;
+//   2. ELU once per element, in place in the window;
+//   3. per 32 steps: hidden = W1 * window (3 taps at shifted rows) + b1, rounded to bf16 (the value the three-launch form
+//      stores), ELU, into a wave-private LDS stage laid out as MFMA B fragments; W3 * stage accumulates onto the shortcut;
+//      the stage's rows go to t_act (when the caller wants the backward's ELU'(t) source); bias, one rounding, rows through
+//      the stage, 16-byte row-contiguous stores.
+// All three weight matrices live in registers as MFMA A fragments (36 / 96 registers), biases in LDS.
+#include "swin_common.h"
+#include <stdlib.h>
+
+typedef float ru_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int NT, int RD, int WPB>
+struct RuCfg {
+    static constexpr int H = C / 2;                        // hidden channels
+    static constexpr int NR = NT * 32;                     // output steps per tile
+    static constexpr int ROWB = C * 2;
+    static constexpr int CPR = ROWB / 16;
+    static constexpr int RPL = 16 / CPR;
+    static constexpr int WROWS = NR + 2;
+    static constexpr int WCH = WROWS * CPR;
+    static constexpr int NLW = (WCH + 63) / 64;
+    static constexpr int SLOT = ((WROWS * ROWB + 255) / 256) * 256;
+    static constexpr int MT = C / 32;
+    static constexpr int KSC = C / 16;                     // K-steps of one tap (and of the shortcut)
+    static constexpr int KS1 = 3 * KSC;
+    static constexpr int KS3 = H / 16;
+    static constexpr int TROW = H * 2 + 16;                // staged hidden row: 48 / 80 bytes, 16 lanes of a b128 read hit 16 different slots
+    static constexpr int YROW = 32 * 2 + 8;                // staged output half-row (32 channels)
+    static constexpr int STAGE = ((32 * (TROW > YROW ? TROW : YROW) + 255) / 256) * 256;
+    static constexpr int NTB = C == 64 ? 1 : 2;            // 32 rows further = 16 / 8 lines further: the swizzle repeats every NTB sub-tiles
+    static constexpr int WAVE_LDS = RD * SLOT + STAGE;
+    static constexpr int BIAS_OFF = WPB * WAVE_LDS;
+    static constexpr int LDS = BIAS_OFF + 512;             // [C] b_sc + b3, [H] b1 (fp32)
+    static_assert(C == 32 || C == 64, "C");
+    static_assert(NT % NTB == 0, "NT");
+    static_assert((RD - 1) * NLW <= 63, "vmcnt range");
+    static_assert(WAVE_LDS % 256 == 0, "lines");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+template <int C, int NT, int RD, int WPB>
+__global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params p, int tiles_per_item, int total) {
+    typedef RuCfg<C, NT, RD, WPB> G;
+    constexpr int H = G::H, NR = G::NR, ROWB = G::ROWB, CPR = G::CPR, RPL = G::RPL, WROWS = G::WROWS, WCH = G::WCH, NLW = G::NLW;
+    constexpr int SLOT = G::SLOT, MT = G::MT, KSC = G::KSC, KS1 = G::KS1, KS3 = G::KS3, TROW = G::TROW, YROW = G::YROW, NTB = G::NTB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+    char* const ring = smem + wid * G::WAVE_LDS;
+    char* const stage = ring + RD * SLOT;
+    float* const bsum = (float*)(smem + G::BIAS_OFF);
+    float* const b1s = bsum + C;
+    for (int i = tid; i < C + H; i += WPB * 64) bsum[i] = i < C ? p.b_sc[i] + p.b3[i] : p.b1[i - C];
+    __syncthreads();
+
+    // A fragment (mt, ks) of lane (r, h) of a row-major [M][K] matrix: w[mt*32 + r][ks*16 + h*8 .. +8]
+    const bf16_t* __restrict__ wsc = (const bf16_t*)p.w_sc;
+    const bf16_t* __restrict__ w1 = (const bf16_t*)p.w1;
+    const bf16_t* __restrict__ w3 = (const bf16_t*)p.w3;
+    bf16x8 asc[MT][KSC], a1[KS1], a3[MT][KS3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) asc[mt][ks] = *(gfrag_ptr_t)(wsc + (size_t)(mt * 32 + r) * C + ks * 16 + h * 8);
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) a3[mt][ks] = *(gfrag_ptr_t)(w3 + (size_t)(mt * 32 + r) * H + ks * 16 + h * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) a1[ks] = *(gfrag_ptr_t)sw_sel(r < H, (uintptr_t)(w1 + (size_t)r * (3 * C) + ks * 16 + h * 8), zero);
+
+    // window fill pattern (conv_swin.hip): LDS slot P = i*64 + lane holds logical slot (P & 15) ^ (line & 15) of line P >> 4
+    // (load i + 4 is 16 lines further: the same swizzle, 4096 bytes and 16*RPL rows on)
+    constexpr int NLD = NLW < 4 ? NLW : 4;
+    int wrow[NLD], woff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int P = i * 64 + lane;
+        const int line = P >> 4, sl = (P & 15) ^ (line & 15);
+        wrow[i] = line * RPL + sl / CPR;
+        woff[i] = wrow[i] * ROWB + (sl % CPR) * 16;
+    }
+    // B fragment (nt, ks) of lane (r, h): window row nt*32 + r + tap, chunk ch; sub-tile nt + NTB sits 4096 bytes further
+    int foff[NTB][KS1];
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int tap = (ks * 16) / C, ch = ((ks * 16) % C) / 8 + h;
+            const int row = nb * 32 + r + tap;
+            const int line = row / RPL, sl = (row % RPL) * CPR + ch;
+            foff[nb][ks] = line * 256 + ((sl ^ (line & 15)) << 4);
+        }
+
+    bf16_t* __restrict__ y = (bf16_t*)p.y;
+    bf16_t* __restrict__ tact = (bf16_t*)p.t_act;
+    const int L = p.L;
+
+    auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+        const bool valid = t < total;
+        const int tt = valid ? t : 0;
+        const int b = tt / tiles_per_item, tl0 = (tt - b * tiles_per_item) * NR;
+        const int R0 = tl0 - 2;
+        const uintptr_t xb = (uintptr_t)p.x + (size_t)b * L * ROWB;
+        char* const dst = ring + slot * SLOT;
+        if (valid && R0 >= 0 && R0 + WROWS <= L) {  // every row of the window is a row of the item (wave-uniform)
+            const uintptr_t base = xb + (size_t)R0 * ROWB;
+#pragma unroll
+            for (int i = 0; i < NLW; ++i)
+                if ((i + 1) * 64 <= WCH || lane < WCH - i * 64) sw_glds16(base + woff[i & 3] + (i >> 2) * 4096, dst + i * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLW; ++i) {
+                int R = R0 + wrow[i & 3] + (i >> 2) * 16 * RPL;
+                if (R < 0) R = -R;  // reflect-left padding of the causal conv (HF modeling_encodec.py:157-176)
+                const bool ok = valid && R < L;
+                if ((i + 1) * 64 <= WCH || lane < WCH - i * 64)
+                    sw_glds16(sw_sel(ok, xb + (size_t)(ok ? R : 0) * ROWB + (woff[i & 3] - wrow[i & 3] * ROWB), zero), dst + i * 1024);
+            }
+        }
+    };
+
+    const int nw = gridDim.x * WPB;
+    int t = blockIdx.x * WPB + wid;
+#pragma unroll
+    for (int d = 0; d < RD - 1; ++d) issue(t + d * nw, d);
+
+    for (int it = 0; t < total; t += nw, ++it) {
+        asm volatile("" ::: "memory");
+        issue(t + (RD - 1) * nw, (it + RD - 1) % RD);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * NLW) : "memory");
+        char* const Wl = ring + (it % RD) * SLOT;
+        const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NR;
+
+        // 1. shortcut on the raw rows (tap 2 of the window = the step itself)
+        f32x16 acc[NT][MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                const bf16x8 xb = *(const bf16x8*)(Wl + foff[nt % NTB][2 * KSC + ks] + (nt / NTB) * 4096);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[mt][ks], xb, acc[nt][mt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 2. ELU once per element, in place (each lane the chunks it loaded)
+#pragma unroll
+        for (int i = 0; i < NLW; ++i)
+            if ((i + 1) * 64 <= WCH || lane < WCH - i * 64) {
+                char* const q = Wl + (i * 64 + lane) * 16;
+                sw_lds_write16(q, sw_elu8(*(const u32x4*)q));
+            }
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // 3a. hidden rows of these 32 steps
+            f32x16 ta;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ta[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 xb = *(const bf16x8*)(Wl + foff[nt % NTB][ks] + (nt / NTB) * 4096);
+                ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], xb, ta, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q) {  // accumulator (q, i) of lane (r, h): hidden channel 8q + 4h + i of step r
+                const ru_f32x4 bb = *(const ru_f32x4*)(b1s + 8 * q + 4 * h);
+                u32x2 o;
+                o.x = sw_elu2(sw_pack_bf16(ta[4 * q] + bb[0], ta[4 * q + 1] + bb[1]));
+                o.y = sw_elu2(sw_pack_bf16(ta[4 * q + 2] + bb[2], ta[4 * q + 3] + bb[3]));
+                sw_lds_write8(stage + r * TROW + (8 * q + 4 * h) * 2, o);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // 3b. second conv onto the shortcut
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) {
+                const bf16x8 tb = *(const bf16x8*)(stage + r * TROW + (ks * 16 + h * 8) * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[mt][ks], tb, acc[nt][mt], 0, 0, 0);
+            }
+            if (tact) {  // ELU(hidden) for the backward pass: rows of H channels, 16 bytes per lane
+                constexpr int LPRT = H / 8, RPPT = 64 / LPRT;
+#pragma unroll
+                for (int ps = 0; ps < 32 / RPPT; ++ps) {
+                    const int row = ps * RPPT + lane / LPRT, c0 = (lane % LPRT) * 8;
+                    const int tl = tl0 + nt * 32 + row;
+                    const u32x4 v = *(const u32x4*)(stage + row * TROW + c0 * 2);
+                    if (tl < L) *(u32x4*)(tact + ((size_t)b * L + tl) * H + c0) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // 3c. bias, one rounding, rows through the stage (32 channels at a time)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const ru_f32x4 bb = *(const ru_f32x4*)(bsum + mt * 32 + 8 * q + 4 * h);
+                    u32x2 o;
+                    o.x = sw_pack_bf16(acc[nt][mt][4 * q] + bb[0], acc[nt][mt][4 * q + 1] + bb[1]);
+                    o.y = sw_pack_bf16(acc[nt][mt][4 * q + 2] + bb[2], acc[nt][mt][4 * q + 3] + bb[3]);
+                    sw_lds_write8(stage + r * YROW + (8 * q + 4 * h) * 2, o);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int row = ps * 16 + (lane >> 2), m0 = (lane & 3) * 8;
+                    const int tl = tl0 + nt * 32 + row;
+                    const u32x2 lo = *(const u32x2*)(stage + row * YROW + m0 * 2), hi = *(const u32x2*)(stage + row * YROW + m0 * 2 + 8);
+                    u32x4 ov;
+                    ov.x = lo.x; ov.y = lo.y; ov.z = hi.x; ov.w = hi.y;
+                    if (tl < L) *(u32x4*)(y + ((size_t)b * L + tl) * C + mt * 32 + m0) = ov;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (prefetches past the end read the zero page; let them land before the LDS goes)
+}
+
+template <int C, int NT, int RD, int WPB>
+static int launch_resunit(const ga_resunit_params& p, hipStream_t s) {
+    typedef RuCfg<C, NT, RD, WPB> G;
+    const int tpi = (p.L + G::NR - 1) / G::NR;
+    const long total = (long)p.B * tpi;
+    if (total <= 0) return GA_OK;
+    if (total > (1L << 30)) return GA_ERR_UNSUPPORTED;
+    auto kern = resunit_fwd_kernel<C, NT, RD, WPB>;
+    static bool attr_set[16] = {};  // per device: the attribute is a property of the loaded function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return GA_ERR_LAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return GA_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    long grid = (total + WPB - 1) / WPB;
+    if (grid > 256) grid = 256;  // one workgroup per CU (its LDS)
+    kern<<<(int)grid, WPB * 64, G::LDS, s>>>(p, tpi, (int)total);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+extern "C" int ga_resunit_fwd(const ga_resunit_params* hp, int dtype, hipStream_t s) {
+    if (!hp) return GA_ERR_ARG;
+    const ga_resunit_params& p = *hp;
+    if (!p.x || !p.y || !p.w_sc || !p.b_sc || !p.w1 || !p.b1 || !p.w3 || !p.b3 || p.B < 0 || p.L < 0) return GA_ERR_ARG;
+    if (dtype != GA_DTYPE_BF16 || (p.C != 32 && p.C != 64) || p.L < 3) return GA_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.t_act | (uintptr_t)p.w_sc | (uintptr_t)p.w1 | (uintptr_t)p.w3) & 15) return GA_ERR_ALIGN;
+    if (p.B == 0) return GA_OK;
+    return p.C == 32 ? launch_resunit<32, 4, 2, 8>(p, s) : launch_resunit<64, 2, 2, 8>(p, s);
+}

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -867,6 +868,44 @@ def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int,
     return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res)
 
 
+FUSE_RESUNIT = os.environ.get("GA_FUSE_RESUNIT", "1") != "0"  # False: a thin residual unit's forward as three ga_conv launches (A/B checks)
+
+
+def resunit_fusable(x: Tensor, g_sc: ConvGeom, g1: ConvGeom, g3: ConvGeom) -> bool:
+    """True when ga_resunit_fwd takes this residual unit: bf16, C in {32, 64} -> C/2 -> C, causal k3 / k1 / k1 shortcut."""
+    c = g_sc.cin
+    return (FUSE_RESUNIT and x.dtype == torch.bfloat16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) and c in (32, 64) and x.shape[1] >= 3
+            and all(g.kind == "cconv" and g.dilation == 1 for g in (g_sc, g1, g3))
+            and (g_sc.cin, g_sc.cout, g_sc.k) == (c, c, 1) and (g1.cin, g1.cout, g1.k) == (c, c // 2, 3)
+            and (g3.cin, g3.cout, g3.k) == (c // 2, c, 1))
+
+
+def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: Tensor, b3_f: Tensor, b3_b: Tensor, want_t: bool):
+    """(y, ELU(hidden) or None) of one residual unit in one launch (ga_resunit_fwd)."""
+    L.require_cuda(x, sc_f, b1_f, b3_f)
+    B, lin, c = x.shape
+    assert x.is_contiguous() and x.dtype == torch.bfloat16
+    for w, n in ((sc_f, c * c), (b1_f, c // 2 * 3 * c), (b3_f, c * c // 2)):
+        assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.numel() >= n
+    for b_, n in ((sc_b, c), (b1_b, c // 2), (b3_b, c)):
+        assert b_.dtype == torch.float32 and b_.numel() == n
+    y = torch.empty_like(x)
+    t = torch.empty((B, lin, c // 2), device=x.device, dtype=x.dtype) if want_t else None
+    p = L.ResunitParams()
+    _fill(p, x=x.data_ptr(), y=y.data_ptr(), t_act=L.ptr(t), w_sc=sc_f.data_ptr(), b_sc=sc_b.data_ptr(), w1=b1_f.data_ptr(),
+          b1=b1_b.data_ptr(), w3=b3_f.data_ptr(), b3=b3_b.data_ptr(), B=B, L=lin, C=c)
+    if PROFILE is None:
+        L.check(L.lib().ga_resunit_fwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_fwd")
+        return y, t
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(L.lib().ga_resunit_fwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_fwd")
+    e1.record()
+    flops = 2.0 * B * lin * (c * c + 3 * c * (c // 2) + (c // 2) * c)
+    PROFILE.append((L.KERNEL_RESUNIT, flops, e0, e1, (B, c, c, 3, lin, 1, 1, L.ACT_ELU), flops))
+    return y, t
+
+
 class ResBlockFrozen(torch.autograd.Function):
     """SEANet residual unit with frozen weights (HF modeling_encodec.py:320-343: shortcut(x) + conv_k1(ELU(conv_k(ELU(x))))) as ONE
     autograd node.  As three ConvFrozen nodes, autograd sums the two gradients that reach x (shortcut and block) with an
@@ -883,6 +922,13 @@ class ResBlockFrozen(torch.autograd.Function):
     def forward(ctx, x, sc_f, sc_d, sc_b, g_sc: ConvGeom, b1_f, b1_d, b1_b, g1: ConvGeom, b3_f, b3_d, b3_b, g3: ConvGeom,
                 elu_mid: bool = False, elu_out: bool = False):
         x = x.contiguous()
+        if not elu_out and resunit_fusable(x, g_sc, g1, g3):
+            # the thin units (32 / 64 channels): one pass over x instead of three launches; the hidden tensor is kept, as ELU(t),
+            # only when a gradient will come back
+            y, t = resunit_forward(x, sc_f, sc_b, b1_f, b1_b, b3_f, b3_b, want_t=ctx.needs_input_grad[0])
+            ctx.geoms, ctx.elu_mid = (g_sc, g1, g3), True
+            ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
+            return y
         sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
         t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
         y = _frozen_forward(g3, t, b3_f, b3_b, ACT_ELU_DONE if elu_mid else L.ACT_ELU, res=sc,

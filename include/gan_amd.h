@@ -161,7 +161,32 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_GEMM_PP 11     /* conv_pp_kernel: 256x256 tiles, wave tile 128x64, ping-pong schedule (deep K, M >= 192) */
 #define GA_KERNEL_CONV_WIN 12    /* conv_win_kernel: input window in LDS, weights streamed (narrow-channel D layers) */
 #define GA_KERNEL_STREAM_WIN 13  /* conv_swin_kernel: M <= 64, 2-4 taps, weights in registers, per-wave ring of input windows in LDS */
+#define GA_KERNEL_RESUNIT 14     /* resunit_fwd_kernel (ga_resunit_fwd below; never returned by ga_conv_kernel_id) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
+
+/* One SEANet residual unit of the frozen decoder, forward, as ONE pass over its input (bf16):
+ *     y = shortcut(x) + conv_k1(ELU(conv_k3(ELU(x))))          C -> C/2 -> C channels, causal k3 with reflect-left padding
+ * replaces: EncodecResnetBlock.forward, HF modeling_encodec.py:320-343 (shortcut conv k1 :333-336, block = ELU, conv k3,
+ *   ELU, conv k1 :326-332), reached through FrozenEncodec.decode_embeddings (lab3_codec_bridge.py:143) -- the three ga_conv
+ *   launches of the unit at the thin end of the decoder (32 and 64 channels at 60000-120000 steps per item), which each read
+ *   and write the unit's largest tensors; here x is read once and y written once.
+ *   x, y [B][L][C] channels-last; weights in ga_conv's packed forward layout (GA_PACK_CONV_FWD): w_sc [C][C], w1 [C/2][3][C],
+ *   w3 [C][C/2]; biases fp32.  t_act (optional, [B][L][C/2]) receives ELU(conv_k3(ELU(x)) + b1), which the data gradient of
+ *   conv_k1 needs (GA_DACT_ELU_FROM_OUT).  The shortcut stays in fp32 until the single rounding of y (the three-launch form
+ *   rounds it to bf16 first).  C in {32, 64}, L >= 3, 16-byte aligned pointers; anything else returns GA_ERR_UNSUPPORTED. */
+typedef struct ga_resunit_params {
+    const void* x;
+    void* y;
+    void* t_act;
+    const void* w_sc;
+    const float* b_sc;
+    const void* w1;
+    const float* b1;
+    const void* w3;
+    const float* b3;
+    int B, L, C;
+} ga_resunit_params;
+int ga_resunit_fwd(const ga_resunit_params* h_params, int dtype, ga_stream_t stream);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
  * fp32 atomics into dw (caller zeroes); dw is in the packed forward layout [M][J][Cin].

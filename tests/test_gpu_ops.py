@@ -1001,18 +1001,73 @@ def test_fused_residual_unit_matches_three_node_form():
     dec.invalidate_packs()
     q = torch.randn(2, 128, 9, device=DEV)
     outs = {}
-    for mode in ("nodes", "fused", "fused+elu"):
-        dec.fuse_resblock, dec.fuse_elu = mode != "nodes", mode == "fused+elu"
-        qq = q.clone().requires_grad_(True)
-        wav = dec(qq)
-        g, = torch.autograd.grad(wav.float().square().sum(), qq)
-        outs[mode] = (wav.detach().float().cpu(), g.float().cpu())
+    old = ops.FUSE_RESUNIT
+    ops.FUSE_RESUNIT = False  # (the thin units' one-launch forward has a test of its own below; it rounds the shortcut once less)
+    try:
+        for mode in ("nodes", "fused", "fused+elu"):
+            dec.fuse_resblock, dec.fuse_elu = mode != "nodes", mode == "fused+elu"
+            qq = q.clone().requires_grad_(True)
+            wav = dec(qq)
+            g, = torch.autograd.grad(wav.float().square().sum(), qq)
+            outs[mode] = (wav.detach().float().cpu(), g.float().cpu())
+    finally:
+        ops.FUSE_RESUNIT = old
     assert torch.equal(outs["fused"][0], outs["nodes"][0])
     close(outs["fused"][1], outs["nodes"][1], 2e-2, "fused residual unit dq")
     # ELU written by the producing epilogues (inside the wide units and in front of the transposed convs behind them): the
     # activation is taken from the fp32 accumulator instead of from its bf16 rounding, so equal only to bf16 accuracy
     close(outs["fused+elu"][0], outs["nodes"][0], 2e-2, "producer-side ELU wav")
     close(outs["fused+elu"][1], outs["nodes"][1], 3e-2, "producer-side ELU dq")
+
+
+@pytest.mark.parametrize("c,lin,B", [(32, 3, 2), (32, 131, 3), (32, 4173, 2), (64, 5, 1), (64, 64, 2), (64, 2013, 3),
+                                     (32, 120000, 2), (64, 60000, 3)])
+def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c, lin, B):
+    """ga_resunit_fwd (the thin residual units of the decoder, HF modeling_encodec.py:320-343, as one pass over x) against the
+    three ga_conv launches it replaces and against torch fp32 on the same bf16-rounded weights: forward to bf16 accuracy
+    (the one-launch form keeps the shortcut in fp32 where the three-launch form rounds it to bf16 before the sum), the hidden
+    tensor it saves for the backward equal to ELU of the three-launch hidden tensor to one bf16 step, and the input gradient of
+    the whole unit (which runs the same three data-gradient launches from that saved tensor) to bf16 accuracy.  Lengths: the
+    reflect padding alone (3, 5), one partial tile, several tiles with a ragged end, and the bench's item lengths."""
+    torch.manual_seed(c + lin)
+    g_sc, g1, g3 = ConvGeom("cconv", c, c, 1), ConvGeom("cconv", c, c // 2, 3), ConvGeom("cconv", c // 2, c, 1)
+    ws = {n: (torch.randn(g.cout, g.cin, g.k) * (1.5 / (g.cin * g.k) ** 0.5)).bfloat16().float() for n, g in (("sc", g_sc), ("b1", g1), ("b3", g3))}
+    bs = {n: torch.randn(g.cout) * 0.1 for n, g in (("sc", g_sc), ("b1", g1), ("b3", g3))}
+    packs = {n: ops.pack_frozen(g, ws[n].to(DEV), None, torch.bfloat16) for n, g in (("sc", g_sc), ("b1", g1), ("b3", g3))}
+    bd = {n: b.to(DEV) for n, b in bs.items()}
+    x = torch.randn(B, lin, c).bfloat16()
+    gy = torch.randn(B, lin, c).bfloat16()
+
+    def run(fuse):
+        old = ops.FUSE_RESUNIT
+        ops.FUSE_RESUNIT = fuse
+        try:
+            xx = x.to(DEV).requires_grad_(True)
+            y = ops.ResBlockFrozen.apply(xx, *packs["sc"], bd["sc"], g_sc, *packs["b1"], bd["b1"], g1, *packs["b3"], bd["b3"], g3, False, False)
+            hidden = y.grad_fn.saved_tensors[1]
+            gx, = torch.autograd.grad(y, xx, gy.to(DEV))
+            with torch.no_grad():  # the frozen items' call: no hidden tensor is written
+                y0 = ops.ResBlockFrozen.apply(x.to(DEV), *packs["sc"], bd["sc"], g_sc, *packs["b1"], bd["b1"], g1, *packs["b3"], bd["b3"], g3, False, False)
+            assert torch.equal(y0, y)
+            return y.detach().float().cpu(), gx.float().cpu(), hidden.detach().float().cpu()
+        finally:
+            ops.FUSE_RESUNIT = old
+
+    y1, gx1, h1 = run(True)
+    y3, gx3, h3 = run(False)
+    assert h1.shape == (B, lin, c // 2)
+    href = F.elu(h3).bfloat16().float()  # (exp2-based ELU in the kernel, expm1 here: one bf16 step apart at most)
+    assert ((h1 - href).abs() <= 2.0 ** -7 * href.abs().clamp_min(1e-3)).all()
+    close(y1, y3, 1e-2, "one-launch unit vs three launches, y")
+    close(gx1, gx3, 1e-2, "one-launch unit vs three launches, dx")
+    if lin <= 5000:
+        xr = x.float().permute(0, 2, 1).requires_grad_(True)
+        t = _ref_conv(g1, xr, ws["b1"], bs["b1"], L.ACT_ELU, 0)
+        yr = _ref_conv(g_sc, xr, ws["sc"], bs["sc"], 0, 0) + _ref_conv(g3, t, ws["b3"], bs["b3"], L.ACT_ELU, 0)
+        gr, = torch.autograd.grad(yr, xr, gy.float().permute(0, 2, 1))
+        close(y1, yr.permute(0, 2, 1), TOL[torch.bfloat16], "one-launch unit vs torch fp32, y")
+        close(gx1, gr.permute(0, 2, 1), TOL[torch.bfloat16], "one-launch unit vs torch fp32, dx")
+        # closer to the fp32 result than the three-launch form (one rounding less): not asserted, both are inside the bf16 bound
 
 
 def test_pack_cache_is_released_with_its_optimizer():
