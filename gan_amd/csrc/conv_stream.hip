@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
     const int erow = lane / LPR, m0 = (lane % LPR) * 8;
     const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
     const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
-    const bool delu = p.dact_mode == GA_DACT_ELU_FROM_IN;
+    const int dmode = p.dact_mode;  // (uniform: the compiler hoists the choice out of the element loop)
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias && m0 < p.M) {
         const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float sv = (float)side[nt][ps][i];
-                        v[i] *= sv > 0.f ? 1.f : (delu ? __expf(sv) : 0.2f);
+                        v[i] *= sv > 0.f ? 1.f : (dmode == GA_DACT_ELU_FROM_IN ? __expf(sv) : dmode == GA_DACT_ELU_FROM_OUT ? sv + 1.f : 0.2f);
                     }
                 }
                 if (SIDE == SIDE_RES) {
@@ -280,7 +280,8 @@ int ga_conv_stream_supported(const ConvParams& p) {
     if (p.res_mode != GA_RES_ADD) return 0;
     if (p.pre_act != GA_ACT_NONE && p.pre_act != GA_ACT_ELU) return 0;
     if (p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
-    if (p.dact_mode != GA_DACT_NONE && p.dact_mode != GA_DACT_ELU_FROM_IN && p.dact_mode != GA_DACT_LRELU_FROM_OUT) return 0;
+    if (p.dact_mode != GA_DACT_NONE && p.dact_mode != GA_DACT_ELU_FROM_IN && p.dact_mode != GA_DACT_LRELU_FROM_OUT &&
+        p.dact_mode != GA_DACT_ELU_FROM_OUT) return 0;
     if (p.dact_mode && !p.dact_src) return 0;
     if (p.accumulate || p.out_f32 || stream_side(p) < 0) return 0;
     if (p.pre_act == GA_ACT_ELU && p.dact_mode) return 0;  // (not instantiated: a forward fuses ELU, a data gradient its derivative)
