@@ -23,7 +23,7 @@ KERNEL_STREAM = 10
 KERNEL_GEMM_PP = 11
 KERNEL_CONV_WIN = 12
 KERNEL_STREAM_WIN = 13
-KERNEL_RESUNIT = 14  # ga_resunit_fwd (not a ga_conv kernel: the benchmark's per-kernel accounting only)
+KERNEL_RESUNIT, KERNEL_RESUNIT_BWD = 14, 15  # ga_resunit_fwd / _bwd (not ga_conv kernels: the benchmark's per-kernel accounting only)
 GEMM_KERNELS = (7, 8, 9, 10, 11, 12, 13)  # MFMA kernels whose operands never pass through a conv window in LDS
 PACK_CONV_FWD, PACK_CONV_DGRAD_S1, PACK_CONV_DGRAD_STRIDED, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3, 4
 RED_ABSDIFF, RED_RELU1M, RED_RELU1P, RED_SUM, RED_SQ = 0, 1, 2, 3, 4
@@ -78,6 +78,10 @@ class ResunitParams(C.Structure):
                [(n, C.c_int) for n in ("B", "L", "C")]
 
 
+class ResunitBwdParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gy", "t_act", "x", "gx", "w_sc_d", "w1_d", "w3_d")] + [(n, C.c_int) for n in ("B", "L", "C")]
+
+
 class LstmParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "bias2", "xg1", "x_in", "y", "h1", "h2", "c1", "c2", "gates1", "gates2",
                                           "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype", "B_save")] + \
@@ -97,6 +101,7 @@ _SIGNATURES = {
     "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
     "ga_conv_splitk_static": [C.POINTER(ConvParams), _I, _P],
     "ga_resunit_fwd": [C.POINTER(ResunitParams), _I, _P],
+    "ga_resunit_bwd": [C.POINTER(ResunitBwdParams), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
     "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],

@@ -265,3 +265,279 @@ extern "C" int ga_resunit_fwd(const ga_resunit_params* hp, int dtype, hipStream_
     if (p.B == 0) return GA_OK;
     return p.C == 32 ? launch_resunit<32, 4, 2, 8>(p, s) : launch_resunit<64, 2, 2, 8>(p, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same unit's input gradient as one pass:
+//     gt = (W3^T gy) * ELU'(hidden)              (from t_act = ELU(hidden): 1 where positive, else t_act + 1)
+//     gx = W_sc^T gy + ( sum_j W1[j]^T gt[n + 2 - j]  (+ the rows folded back from the reflected left pad) ) * ELU'(x)
+// As three ga_conv launches (+ the pad fix-up) it moved 7.5 C-wide passes where 3.5 are needed (gy, x, half-width t_act in; gx
+// out).  Per wave and tile: NW rows of gy, t_act and x (the same rows n0 .. n0+NW-1 of the item: the taps look FORWARD here, so
+// nothing is reflected in the loads) go global -> LDS one tile ahead, exactly 10 direct-to-LDS loads; the tile yields
+// NW - 2 rows of gx.  gy's B fragments feed two products (hidden gradient for all NW rows, shortcut for the output rows); the
+// masked hidden gradient goes through a wave-private stage in B-fragment layout (rounded to bf16 as the three-launch form
+// stores it); the three taps read it at shifted rows; gb stays in fp32 until the one rounding of gx.
+template <int C, int RD, int WPB>
+struct RuBwdCfg {
+    static constexpr int H = C / 2;
+    static constexpr int ROWB = C * 2;
+    static constexpr int NW = 4096 / ROWB;                 // window rows: 32 (C = 64) / 64 (C = 32)
+    static constexpr int NTW = NW / 32;
+    static constexpr int NO = NW - 2;                      // output rows per tile
+    static constexpr int CPR = ROWB / 16, RPL = 16 / CPR;  // gy / x rows
+    static constexpr int TROWB = H * 2, CPRT = TROWB / 16, RPLT = 16 / CPRT;
+    static constexpr int GY_OFF = 0, T_OFF = 4096, X_OFF = 6144, SLOT = 10240;
+    static constexpr int NLOAD = 10;                       // 4 + 2 + 4 loads of 1024 bytes
+    static constexpr int MT = C / 32;
+    static constexpr int KSC = C / 16;
+    static constexpr int KS3 = H / 16;
+    static constexpr int TROW = H * 2 + 16;                // staged hidden-gradient row
+    static constexpr int GSTAGE = (((NW + 2) * TROW + 255) / 256) * 256;
+    static constexpr int YROW = 32 * 2 + 8;
+    static constexpr int YSTAGE = 2304;
+    static constexpr int WAVE_LDS = RD * SLOT + GSTAGE + YSTAGE;
+    static constexpr int LDS = WPB * WAVE_LDS;
+    static_assert(C == 32 || C == 64, "C");
+    static_assert((RD - 1) * NLOAD <= 63, "vmcnt range");
+    static_assert(WAVE_LDS % 256 == 0, "lines");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+template <int C, int RD, int WPB>
+__global__ __launch_bounds__(WPB * 64) void resunit_bwd_kernel(ga_resunit_bwd_params p, int tiles_per_item, int total) {
+    typedef RuBwdCfg<C, RD, WPB> G;
+    constexpr int H = G::H, ROWB = G::ROWB, NW = G::NW, NTW = G::NTW, NO = G::NO, CPR = G::CPR, RPL = G::RPL;
+    constexpr int TROWB = G::TROWB, CPRT = G::CPRT, RPLT = G::RPLT, SLOT = G::SLOT, MT = G::MT, KSC = G::KSC, KS3 = G::KS3;
+    constexpr int TROW = G::TROW, YROW = G::YROW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+    char* const ring = smem + wid * G::WAVE_LDS;
+    char* const gstage = ring + RD * SLOT;
+    char* const ystage = gstage + G::GSTAGE;
+
+    // A fragments of the data-gradient packs (GA_PACK_CONV_DGRAD_S1: [rows = input channels][tap, flipped][output channels])
+    const bf16_t* __restrict__ wsc = (const bf16_t*)p.w_sc_d;  // [C][C]
+    const bf16_t* __restrict__ w1 = (const bf16_t*)p.w1_d;     // [C][3][H]
+    const bf16_t* __restrict__ w3 = (const bf16_t*)p.w3_d;     // [H][C]
+    bf16x8 asc[MT][KSC], a1[MT][3 * KS3], a3[KSC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) asc[mt][ks] = *(gfrag_ptr_t)(wsc + (size_t)(mt * 32 + r) * C + ks * 16 + h * 8);
+#pragma unroll
+        for (int ks = 0; ks < 3 * KS3; ++ks) a1[mt][ks] = *(gfrag_ptr_t)(w1 + (size_t)(mt * 32 + r) * (3 * H) + ks * 16 + h * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) a3[ks] = *(gfrag_ptr_t)sw_sel(r < H, (uintptr_t)(w3 + (size_t)r * C + ks * 16 + h * 8), zero);
+
+    // fill patterns: load i of a region puts 16 bytes per lane at LDS slot P = i*64 + lane of the region, which holds logical
+    // slot (P & 15) ^ (line & 15) of line P >> 4 (the swizzle of conv_swin.hip, applied to the source address)
+    int woffx[4], wofft[2];  // byte offset inside the region's rows of the item
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int P = i * 64 + lane, line = P >> 4, sl = (P & 15) ^ (line & 15);
+        woffx[i] = (line * RPL + sl / CPR) * ROWB + (sl % CPR) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int P = i * 64 + lane, line = P >> 4, sl = (P & 15) ^ (line & 15);
+        wofft[i] = (line * RPLT + sl / CPRT) * TROWB + (sl % CPRT) * 16;
+    }
+    // reads.  gy B fragment (nt, ks) of lane (r, h): row nt*32 + r, chunk 2 ks + h
+    int foff[NTW][KSC];
+    // t_act / x in the ACCUMULATOR layout: element (q, i) of lane (r, h) is channel 8q + 4h + i of row r: 8 bytes at chunk q (+ 8h)
+    int toff[NTW][H / 8], xoff[NTW][C / 8];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int row = nt * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            const int line = row / RPL, sl = (row % RPL) * CPR + 2 * ks + h;
+            foff[nt][ks] = G::GY_OFF + line * 256 + ((sl ^ (line & 15)) << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < H / 8; ++q) {
+            const int line = row / RPLT, sl = (row % RPLT) * CPRT + q;
+            toff[nt][q] = G::T_OFF + line * 256 + ((sl ^ (line & 15)) << 4) + 8 * h;
+        }
+#pragma unroll
+        for (int q = 0; q < C / 8; ++q) {
+            const int line = row / RPL, sl = (row % RPL) * CPR + q;
+            xoff[nt][q] = G::X_OFF + line * 256 + ((sl ^ (line & 15)) << 4) + 8 * h;
+        }
+    }
+
+    bf16_t* __restrict__ gx = (bf16_t*)p.gx;
+    const int L = p.L;
+
+    auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+        const bool valid = t < total;
+        const int tt = valid ? t : 0;
+        const int b = tt / tiles_per_item, R0 = (tt - b * tiles_per_item) * NO;
+        const uintptr_t gyb = (uintptr_t)p.gy + ((size_t)b * L + R0) * ROWB;
+        const uintptr_t xb = (uintptr_t)p.x + ((size_t)b * L + R0) * ROWB;
+        const uintptr_t tb = (uintptr_t)p.t_act + ((size_t)b * L + R0) * TROWB;
+        char* const dst = ring + slot * SLOT;
+        if (valid && R0 + NW <= L) {  // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw_glds16(gyb + woffx[i], dst + G::GY_OFF + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sw_glds16(tb + wofft[i], dst + G::T_OFF + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw_glds16(xb + woffx[i], dst + G::X_OFF + i * 1024);
+        } else {  // rows past the end of the item: zeros (gy = 0 there makes the hidden gradient 0, as the three-launch form has it)
+            const int left = valid ? L - R0 : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw_glds16(sw_sel(woffx[i] / ROWB < left, gyb + woffx[i], zero), dst + G::GY_OFF + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sw_glds16(sw_sel(wofft[i] / TROWB < left, tb + wofft[i], zero), dst + G::T_OFF + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw_glds16(sw_sel(woffx[i] / ROWB < left, xb + woffx[i], zero), dst + G::X_OFF + i * 1024);
+        }
+    };
+
+    const int nw = gridDim.x * WPB;
+    int t = blockIdx.x * WPB + wid;
+#pragma unroll
+    for (int d = 0; d < RD - 1; ++d) issue(t + d * nw, d);
+
+    for (int it = 0; t < total; t += nw, ++it) {
+        asm volatile("" ::: "memory");
+        issue(t + (RD - 1) * nw, (it + RD - 1) % RD);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * G::NLOAD) : "memory");
+        char* const Wl = ring + (it % RD) * SLOT;
+        const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NO;
+
+        // 1. hidden gradient of every window row, masked, to the stage
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            f32x16 ga;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ga[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks], *(const bf16x8*)(Wl + foff[nt][ks]), ga, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q) {
+                const u32x2 tv = *(const u32x2*)(Wl + toff[nt][q]);
+                float m[4];
+                m[0] = __uint_as_float(tv.x << 16); m[1] = __uint_as_float(tv.x & 0xffff0000u);
+                m[2] = __uint_as_float(tv.y << 16); m[3] = __uint_as_float(tv.y & 0xffff0000u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = ga[4 * q + i] * (m[i] > 0.f ? 1.f : m[i] + 1.f);
+                u32x2 o;
+                o.x = sw_pack_bf16(m[0], m[1]);
+                o.y = sw_pack_bf16(m[2], m[3]);
+                sw_lds_write8(gstage + (nt * 32 + r) * TROW + (8 * q + 4 * h) * 2, o);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // 2. per 32 output rows: three taps of the hidden gradient, ELU'(x), the shortcut on top, one rounding
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            f32x16 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) {
+                    const bf16x8 gb = *(const bf16x8*)(gstage + (nt * 32 + r + j) * TROW + (ks * 16 + h * 8) * 2);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[mt][j * KS3 + ks], gb, acc[mt], 0, 0, 0);
+                }
+            if (nt == 0 && tl0 == 0) {
+                // the reflected left pad of the causal conv (HF modeling_encodec.py:157-176: padded row -l is row l): the gradient of
+                // padded rows -1, -2 returns to rows 1, 2 -- row l takes tap j of hidden-gradient row j - l, 1 <= l <= j
+#pragma unroll
+                for (int j = 1; j < 3; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < KS3; ++ks) {
+                        const bool on = r >= 1 && r <= j;
+                        bf16x8 gb = *(const bf16x8*)(gstage + (on ? j - r : 0) * TROW + (ks * 16 + h * 8) * 2);
+                        if (!on) gb = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[mt][j * KS3 + ks], gb, acc[mt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x2 xv = *(const u32x2*)(Wl + xoff[nt][mt * 4 + q]);
+                    float m[4];
+                    m[0] = __uint_as_float(xv.x << 16); m[1] = __uint_as_float(xv.x & 0xffff0000u);
+                    m[2] = __uint_as_float(xv.y << 16); m[3] = __uint_as_float(xv.y & 0xffff0000u);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[mt][4 * q + i] *= m[i] > 0.f ? 1.f : __builtin_amdgcn_exp2f(m[i] * 1.4426950408889634f);
+                }
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                const bf16x8 gf = *(const bf16x8*)(Wl + foff[nt][ks]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[mt][ks], gf, acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x2 o;
+                    o.x = sw_pack_bf16(acc[mt][4 * q], acc[mt][4 * q + 1]);
+                    o.y = sw_pack_bf16(acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+                    sw_lds_write8(ystage + r * YROW + (8 * q + 4 * h) * 2, o);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int row = ps * 16 + (lane >> 2), m0 = (lane & 3) * 8;
+                    const int wr = nt * 32 + row, tl = tl0 + wr;
+                    const u32x2 lo = *(const u32x2*)(ystage + row * YROW + m0 * 2), hi = *(const u32x2*)(ystage + row * YROW + m0 * 2 + 8);
+                    u32x4 ov;
+                    ov.x = lo.x; ov.y = lo.y; ov.z = hi.x; ov.w = hi.y;
+                    if (wr < NO && tl < L) *(u32x4*)(gx + ((size_t)b * L + tl) * C + mt * 32 + m0) = ov;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int C, int RD, int WPB>
+static int launch_resunit_bwd(const ga_resunit_bwd_params& p, hipStream_t s) {
+    typedef RuBwdCfg<C, RD, WPB> G;
+    const int tpi = (p.L + G::NO - 1) / G::NO;
+    const long total = (long)p.B * tpi;
+    if (total <= 0) return GA_OK;
+    if (total > (1L << 30)) return GA_ERR_UNSUPPORTED;
+    auto kern = resunit_bwd_kernel<C, RD, WPB>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return GA_ERR_LAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return GA_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    long grid = (total + WPB - 1) / WPB;
+    if (grid > 256) grid = 256;
+    kern<<<(int)grid, WPB * 64, G::LDS, s>>>(p, tpi, (int)total);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+extern "C" int ga_resunit_bwd(const ga_resunit_bwd_params* hp, int dtype, hipStream_t s) {
+    if (!hp) return GA_ERR_ARG;
+    const ga_resunit_bwd_params& p = *hp;
+    if (!p.gy || !p.t_act || !p.x || !p.gx || !p.w_sc_d || !p.w1_d || !p.w3_d || p.B < 0 || p.L < 0) return GA_ERR_ARG;
+    if (dtype != GA_DTYPE_BF16 || (p.C != 32 && p.C != 64) || p.L < 3) return GA_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.gy | (uintptr_t)p.t_act | (uintptr_t)p.x | (uintptr_t)p.gx | (uintptr_t)p.w_sc_d | (uintptr_t)p.w1_d | (uintptr_t)p.w3_d) & 15)
+        return GA_ERR_ALIGN;
+    if (p.B == 0) return GA_OK;
+    return p.C == 32 ? launch_resunit_bwd<32, 2, 6>(p, s) : launch_resunit_bwd<64, 2, 6>(p, s);
+}

@@ -906,6 +906,33 @@ def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: T
     return y, t
 
 
+FUSE_RESUNIT_BWD = os.environ.get("GA_FUSE_RESUNIT_BWD", "1") != "0"  # False: the unit's data gradient as three ga_conv launches + the pad fix-up
+
+
+def resunit_backward(gy: Tensor, t_act: Tensor, x: Tensor, sc_d: Tensor, b1_d: Tensor, b3_d: Tensor) -> Tensor:
+    """dL/dx of one residual unit in one launch (ga_resunit_bwd) from dL/dy, the saved ELU(hidden) and x."""
+    L.require_cuda(gy, t_act, x, sc_d, b1_d, b3_d)
+    B, lin, c = x.shape
+    assert gy.shape == x.shape and tuple(t_act.shape) == (B, lin, c // 2)
+    for a in (gy, t_act, x, sc_d, b1_d, b3_d):
+        assert a.is_contiguous() and a.dtype == torch.bfloat16
+    assert sc_d.numel() >= c * c and b1_d.numel() >= c * 3 * (c // 2) and b3_d.numel() >= (c // 2) * c
+    gx = torch.empty_like(x)
+    p = L.ResunitBwdParams()
+    _fill(p, gy=gy.data_ptr(), t_act=t_act.data_ptr(), x=x.data_ptr(), gx=gx.data_ptr(), w_sc_d=sc_d.data_ptr(), w1_d=b1_d.data_ptr(),
+          w3_d=b3_d.data_ptr(), B=B, L=lin, C=c)
+    if PROFILE is None:
+        L.check(L.lib().ga_resunit_bwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_bwd")
+        return gx
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(L.lib().ga_resunit_bwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_bwd")
+    e1.record()
+    flops = 2.0 * B * lin * (c * c + 3 * c * (c // 2) + (c // 2) * c)
+    PROFILE.append((L.KERNEL_RESUNIT_BWD, flops, e0, e1, (B, c, c, 3, lin, 1, 1, 0), flops))
+    return gx
+
+
 class ResBlockFrozen(torch.autograd.Function):
     """SEANet residual unit with frozen weights (HF modeling_encodec.py:320-343: shortcut(x) + conv_k1(ELU(conv_k(ELU(x))))) as ONE
     autograd node.  As three ConvFrozen nodes, autograd sums the two gradients that reach x (shortcut and block) with an
@@ -926,9 +953,10 @@ class ResBlockFrozen(torch.autograd.Function):
             # the thin units (32 / 64 channels): one pass over x instead of three launches; the hidden tensor is kept, as ELU(t),
             # only when a gradient will come back
             y, t = resunit_forward(x, sc_f, sc_b, b1_f, b1_b, b3_f, b3_b, want_t=ctx.needs_input_grad[0])
-            ctx.geoms, ctx.elu_mid = (g_sc, g1, g3), True
+            ctx.geoms, ctx.elu_mid, ctx.one_launch = (g_sc, g1, g3), True, True
             ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
             return y
+        ctx.one_launch = False
         sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
         t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
         y = _frozen_forward(g3, t, b3_f, b3_b, ACT_ELU_DONE if elu_mid else L.ACT_ELU, res=sc,
@@ -944,6 +972,8 @@ class ResBlockFrozen(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous().to(x.dtype)
+            if ctx.one_launch and FUSE_RESUNIT_BWD:
+                return (resunit_backward(gy, t, x, sc_d, b1_d, b3_d),) + (None,) * 14
             gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_OUT if ctx.elu_mid else L.DACT_ELU_FROM_IN, dact_src=t)
             gb = conv_dgrad(g1, gt, b1_d, x.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
             gx = conv_dgrad(g_sc, gy, sc_d, x.shape[1], res=gb)

@@ -162,6 +162,7 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_CONV_WIN 12    /* conv_win_kernel: input window in LDS, weights streamed (narrow-channel D layers) */
 #define GA_KERNEL_STREAM_WIN 13  /* conv_swin_kernel: M <= 64, 2-4 taps, weights in registers, per-wave ring of input windows in LDS */
 #define GA_KERNEL_RESUNIT 14     /* resunit_fwd_kernel (ga_resunit_fwd below; never returned by ga_conv_kernel_id) */
+#define GA_KERNEL_RESUNIT_BWD 15 /* resunit_bwd_kernel (ga_resunit_bwd) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* One SEANet residual unit of the frozen decoder, forward, as ONE pass over its input (bf16):
@@ -187,6 +188,23 @@ typedef struct ga_resunit_params {
     int B, L, C;
 } ga_resunit_params;
 int ga_resunit_fwd(const ga_resunit_params* h_params, int dtype, ga_stream_t stream);
+/* The same unit's input gradient as one pass (autograd of the call above, reached from loss_g.backward(),
+ * lab3_codec_train.py:588):
+ *     gt = (W3^T gy) * ELU'(hidden)          ELU' taken from t_act = ELU(hidden), as GA_DACT_ELU_FROM_OUT
+ *     gx = W_sc^T gy + (conv_k3^T gt, with the rows of the reflected left pad folded back) * ELU'(x)
+ * replaces the unit's three data-gradient ga_conv launches and the pad fix-up launch.  Weights in ga_conv's data-gradient
+ * layout (GA_PACK_CONV_DGRAD_S1): w_sc_d [C][1][C], w1_d [C][3][C/2], w3_d [C/2][1][C].  Same shape limits as ga_resunit_fwd. */
+typedef struct ga_resunit_bwd_params {
+    const void* gy;
+    const void* t_act;
+    const void* x;
+    void* gx;
+    const void* w_sc_d;
+    const void* w1_d;
+    const void* w3_d;
+    int B, L, C;
+} ga_resunit_bwd_params;
+int ga_resunit_bwd(const ga_resunit_bwd_params* h_params, int dtype, ga_stream_t stream);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
  * fp32 atomics into dw (caller zeroes); dw is in the packed forward layout [M][J][Cin].

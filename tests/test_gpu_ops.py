@@ -1038,9 +1038,9 @@ def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c
     x = torch.randn(B, lin, c).bfloat16()
     gy = torch.randn(B, lin, c).bfloat16()
 
-    def run(fuse):
-        old = ops.FUSE_RESUNIT
-        ops.FUSE_RESUNIT = fuse
+    def run(fuse, fuse_bwd=False):
+        old = ops.FUSE_RESUNIT, ops.FUSE_RESUNIT_BWD
+        ops.FUSE_RESUNIT, ops.FUSE_RESUNIT_BWD = fuse, fuse_bwd
         try:
             xx = x.to(DEV).requires_grad_(True)
             y = ops.ResBlockFrozen.apply(xx, *packs["sc"], bd["sc"], g_sc, *packs["b1"], bd["b1"], g1, *packs["b3"], bd["b3"], g3, False, False)
@@ -1051,10 +1051,15 @@ def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c
             assert torch.equal(y0, y)
             return y.detach().float().cpu(), gx.float().cpu(), hidden.detach().float().cpu()
         finally:
-            ops.FUSE_RESUNIT = old
+            ops.FUSE_RESUNIT, ops.FUSE_RESUNIT_BWD = old
 
     y1, gx1, h1 = run(True)
     y3, gx3, h3 = run(False)
+    # ga_resunit_bwd: the unit's input gradient in one launch (hidden gradient, three taps, the reflected pad's rows folded back,
+    # ELU'(x), shortcut) against the three data-gradient launches + fix-up launch on the same saved tensors
+    y1b, gx1b, _ = run(True, True)
+    assert torch.equal(y1b, y1)
+    close(gx1b, gx1, 1e-2, "one-launch input gradient vs three launches")
     assert h1.shape == (B, lin, c // 2)
     href = F.elu(h3).bfloat16().float()  # (exp2-based ELU in the kernel, expm1 here: one bf16 step apart at most)
     assert ((h1 - href).abs() <= 2.0 ** -7 * href.abs().clamp_min(1e-3)).all()
@@ -1067,6 +1072,7 @@ def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c
         gr, = torch.autograd.grad(yr, xr, gy.float().permute(0, 2, 1))
         close(y1, yr.permute(0, 2, 1), TOL[torch.bfloat16], "one-launch unit vs torch fp32, y")
         close(gx1, gr.permute(0, 2, 1), TOL[torch.bfloat16], "one-launch unit vs torch fp32, dx")
+        close(gx1b, gr.permute(0, 2, 1), TOL[torch.bfloat16], "one-launch input gradient vs torch fp32")
         # closer to the fp32 result than the three-launch form (one rounding less): not asserted, both are inside the bf16 bound
 
 
