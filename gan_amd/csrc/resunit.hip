@@ -47,10 +47,19 @@ struct RuCfg {
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int C, int NT, int RD, int WPB>
+typedef float ru_f32x4b __attribute__((ext_vector_type(4)));
+
+// TAIL (C = 32 only): the decoder's last layer behind the unit -- wav = conv_k7(ELU(y)) + b (HF modeling_encodec.py: the decoder's
+// closing nn.ELU + EncodecConv1d(32, 1, 7)) -- in the same pass, for callers that need no gradient: y is never written.  A tile's
+// 128 rows of y (bias, one rounding to bf16: the bits ga_resunit_fwd would store; ELU) go back into the tile's own, by then
+// dead, input window, in the window layout of conv_swin1_kernel, whose four MFMA chains then produce 122 samples: the tile
+// stride is NR - 6 and every tile recomputes the six rows of y in front of its samples (the first tile of an item reflects them).
+template <int C, int NT, int RD, int WPB, bool TAIL>
 __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params p, int tiles_per_item, int total) {
     typedef RuCfg<C, NT, RD, WPB> G;
-    constexpr int H = G::H, NR = G::NR, ROWB = G::ROWB, CPR = G::CPR, RPL = G::RPL, WROWS = G::WROWS, WCH = G::WCH, NLW = G::NLW;
+    static_assert(!TAIL || (C == 32 && NT == 4), "tail form");
+    constexpr int HALO = TAIL ? 6 : 0, NRO = G::NR - HALO;  // rows of y recomputed in front of a tile; tile stride
+    constexpr int H = G::H, ROWB = G::ROWB, CPR = G::CPR, RPL = G::RPL, WROWS = G::WROWS, WCH = G::WCH, NLW = G::NLW;
     constexpr int SLOT = G::SLOT, MT = G::MT, KSC = G::KSC, KS1 = G::KS1, KS3 = G::KS3, TROW = G::TROW, YROW = G::YROW, NTB = G::NTB;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -107,10 +116,37 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
     bf16_t* __restrict__ tact = (bf16_t*)p.t_act;
     const int L = p.L;
 
+    // TAIL: A fragments of the k7 filter (conv_swin1_kernel: rows 0/4/8/12 of the 16-row operand carry it), fragment offsets of
+    // chain c, tap j (window row 4*n16 + c + j, chunk g), where this lane's four y channels of a row go (chunk q, + 8h bytes)
+    constexpr int JL = 7;
+    const int n16 = lane & 15, g4 = lane >> 4;
+    bf16x8 a7[TAIL ? JL : 1];
+    int xo7[TAIL ? JL + 3 : 1], yoff[TAIL ? 2 : 1][TAIL ? 4 : 1];
+    float blast = 0.f;
+    if (TAIL) {
+#pragma unroll
+        for (int j = 0; j < JL; ++j) a7[j] = *(gfrag_ptr_t)sw_sel((n16 & 3) == 0, (uintptr_t)p.w_last + (size_t)(j * C + g4 * 8) * 2, zero);
+#pragma unroll
+        for (int sft = 0; sft < JL + 3; ++sft) {
+            const int row = 4 * n16 + sft;
+            const int line = row / RPL, sl = (row % RPL) * CPR + g4;
+            xo7[sft] = line * 256 + ((sl ^ (line & 15)) << 4);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = nb * 32 + r;
+                const int line = row / RPL, sl = (row % RPL) * CPR + q;
+                yoff[nb][q] = line * 256 + ((sl ^ (line & 15)) << 4) + 8 * h;
+            }
+        blast = p.b_last ? p.b_last[0] : 0.f;
+    }
+
     auto issue = [&](int t, int slot) __attribute__((always_inline)) {
         const bool valid = t < total;
         const int tt = valid ? t : 0;
-        const int b = tt / tiles_per_item, tl0 = (tt - b * tiles_per_item) * NR;
+        const int b = tt / tiles_per_item, tl0 = (tt - b * tiles_per_item) * NRO - HALO;
         const int R0 = tl0 - 2;
         const uintptr_t xb = (uintptr_t)p.x + (size_t)b * L * ROWB;
         char* const dst = ring + slot * SLOT;
@@ -141,7 +177,7 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
         issue(t + (RD - 1) * nw, (it + RD - 1) % RD);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * NLW) : "memory");
         char* const Wl = ring + (it % RD) * SLOT;
-        const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NR;
+        const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NRO - HALO;  // item row of the tile's first row of y
 
         // 1. shortcut on the raw rows (tap 2 of the window = the step itself)
         f32x16 acc[NT][MT];
@@ -206,6 +242,7 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (TAIL) continue;
             // 3c. bias, one rounding, rows through the stage (32 channels at a time)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -230,18 +267,60 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (TAIL) {
+            // every read of the input window is done: ELU(y) takes its place (row w of the window = row tl0 + w of the item)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const ru_f32x4 bb = *(const ru_f32x4*)(bsum + 8 * q + 4 * h);
+                    u32x2 o;
+                    o.x = sw_elu2(sw_pack_bf16(acc[nt][0][4 * q] + bb[0], acc[nt][0][4 * q + 1] + bb[1]));
+                    o.y = sw_elu2(sw_pack_bf16(acc[nt][0][4 * q + 2] + bb[2], acc[nt][0][4 * q + 3] + bb[3]));
+                    sw_lds_write8(Wl + yoff[nt & 1][q] + (nt >> 1) * 4096, o);
+                }
+            __builtin_amdgcn_wave_barrier();
+            if (tl0 < 0) {  // first tile of an item: rows -6 .. -1 of the causal conv's reflected pad are rows 6 .. 1
+                const int w = lane >> 2, c = lane & 3;  // lanes 0..23: chunk c of window row w <- window row 12 - w
+                if (w < HALO) {
+                    const int rs = 2 * HALO - w;
+                    const int ls = rs / RPL, ss = (rs % RPL) * CPR + c, ld = w / RPL, sd = (w % RPL) * CPR + c;
+                    const u32x4 v = *(const u32x4*)(Wl + ls * 256 + ((ss ^ (ls & 15)) << 4));
+                    sw_lds_write16(Wl + ld * 256 + ((sd ^ (ld & 15)) << 4), v);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            float* __restrict__ wav = p.wav;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {  // 64 samples per pass; sample s of the tile reads window rows s .. s + 6
+                ru_f32x4b ch[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ch[c] = ru_f32x4b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < JL; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        ch[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a7[j], *(const bf16x8*)(Wl + xo7[c + j] + sub * 4096), ch[c], 0, 0, 0);
+                const float dot = g4 == 0 ? ch[0][0] : g4 == 1 ? ch[1][0] : g4 == 2 ? ch[2][0] : ch[3][0];
+                const int sidx = sub * 64 + 4 * n16 + g4;
+                const int n = tl0 + HALO + sidx;
+                if (sidx < NRO && n < L) wav[(size_t)b * L + n] = dot + blast;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (prefetches past the end read the zero page; let them land before the LDS goes)
 }
 
-template <int C, int NT, int RD, int WPB>
+template <int C, int NT, int RD, int WPB, bool TAIL>
 static int launch_resunit(const ga_resunit_params& p, hipStream_t s) {
     typedef RuCfg<C, NT, RD, WPB> G;
-    const int tpi = (p.L + G::NR - 1) / G::NR;
+    constexpr int NRO = G::NR - (TAIL ? 6 : 0);
+    const int tpi = (p.L + NRO - 1) / NRO;
     const long total = (long)p.B * tpi;
     if (total <= 0) return GA_OK;
     if (total > (1L << 30)) return GA_ERR_UNSUPPORTED;
-    auto kern = resunit_fwd_kernel<C, NT, RD, WPB>;
+    auto kern = resunit_fwd_kernel<C, NT, RD, WPB, TAIL>;
     static bool attr_set[16] = {};  // per device: the attribute is a property of the loaded function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return GA_ERR_LAUNCH;
@@ -259,11 +338,15 @@ static int launch_resunit(const ga_resunit_params& p, hipStream_t s) {
 extern "C" int ga_resunit_fwd(const ga_resunit_params* hp, int dtype, hipStream_t s) {
     if (!hp) return GA_ERR_ARG;
     const ga_resunit_params& p = *hp;
-    if (!p.x || !p.y || !p.w_sc || !p.b_sc || !p.w1 || !p.b1 || !p.w3 || !p.b3 || p.B < 0 || p.L < 0) return GA_ERR_ARG;
+    if (!p.x || !p.w_sc || !p.b_sc || !p.w1 || !p.b1 || !p.w3 || !p.b3 || p.B < 0 || p.L < 0) return GA_ERR_ARG;
+    if (p.wav ? (p.y || p.t_act || !p.w_last) : !p.y) return GA_ERR_ARG;  // the tail form writes the waveform only
     if (dtype != GA_DTYPE_BF16 || (p.C != 32 && p.C != 64) || p.L < 3) return GA_ERR_UNSUPPORTED;
-    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.t_act | (uintptr_t)p.w_sc | (uintptr_t)p.w1 | (uintptr_t)p.w3) & 15) return GA_ERR_ALIGN;
+    if (p.wav && (p.C != 32 || p.L < 13)) return GA_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.t_act | (uintptr_t)p.w_sc | (uintptr_t)p.w1 | (uintptr_t)p.w3 | (uintptr_t)p.w_last) & 15)
+        return GA_ERR_ALIGN;
     if (p.B == 0) return GA_OK;
-    return p.C == 32 ? launch_resunit<32, 4, 2, 8>(p, s) : launch_resunit<64, 2, 2, 8>(p, s);
+    if (p.wav) return launch_resunit<32, 4, 2, 8, true>(p, s);
+    return p.C == 32 ? launch_resunit<32, 4, 2, 8, false>(p, s) : launch_resunit<64, 2, 2, 8, false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -86,6 +86,7 @@ class SeanetDecoder(nn.Module):
         self.use_library_lstm = False  # True: torch's LSTM op (MIOpen) instead of the gan_amd step kernels (A/B checks)
         self.fuse_resblock = os.environ.get("GA_FUSE_RESBLOCK", "1") != "0"  # False: a residual unit as three autograd nodes (A/B checks)
         self.fuse_elu = os.environ.get("GA_FUSE_ELU", "1") != "0"            # False: every ELU in front of a wide conv is a pass of its own
+        self.fuse_tail = os.environ.get("GA_FUSE_TAIL", "1") != "0"          # False: no-gradient decodes end with separate unit / last-conv launches
         self.ratios = tuple(int(r) for r in ratios)
         c = (2 ** len(self.ratios)) * num_filters
         layers = nn.Module()
@@ -187,10 +188,22 @@ class SeanetDecoder(nn.Module):
                 elu_done = False
             elif kind == "resblock":
                 b1, b3 = getattr(layer.block, "1"), getattr(layer.block, "3")
+                nxt = plan[pos + 1] if pos + 1 < len(plan) else None
+                if (h.dtype == torch.bfloat16 and self.fuse_resblock and self.fuse_tail and nxt is not None and nxt[0] == "elu_conv"
+                        and pos + 2 == len(plan) and not (torch.is_grad_enabled() and h.requires_grad) and h.shape[1] >= 13
+                        and ops.resunit_fusable(h, layer.shortcut.geom, b1.geom, b3.geom) and b3.geom.cout == 32):
+                    # nobody wants a gradient (the frozen items of a step): the last unit and the closing ELU + conv as one launch,
+                    # the unit's output never leaves the chip
+                    last = getattr(self.layers, nxt[1])
+                    if (last.geom.kind, last.geom.cin, last.geom.cout, last.geom.k, last.geom.dilation) == ("cconv", 32, 1, 7, 1):
+                        wav, _ = ops.resunit_forward(
+                            h.contiguous(), self._pack(name + ".sc", layer.shortcut, dtype)[0], layer.shortcut.conv.bias.data,
+                            self._pack(name + ".b1", b1, dtype)[0], b1.conv.bias.data, self._pack(name + ".b3", b3, dtype)[0],
+                            b3.conv.bias.data, want_t=False, last=(self._pack(nxt[1], last, dtype)[0], last.conv.bias.data))
+                        return wav.permute(0, 2, 1)
                 if h.dtype == torch.bfloat16 and self.fuse_resblock:  # one autograd node: no gradient-sum pass over h
                     # where the conv behind an ELU would need a pass to materialise it (wide layers on the gathered-GEMM kernel),
                     # the producing epilogue writes the ELU instead: inside the unit, and for the transposed conv that follows it
-                    nxt = plan[pos + 1] if pos + 1 < len(plan) else None
                     elu_mid = self.fuse_elu and ops.elu_needs_a_pass(b3.geom, torch.empty((h.shape[0], h.shape[1], b3.geom.cin), dtype=h.dtype, device="meta"))
                     elu_out = (self.fuse_elu and nxt is not None and nxt[0] == "elu_convt" and b3.geom.cout >= 128
                                and ops.elu_needs_a_pass(getattr(self.layers, nxt[1]).geom, h))

@@ -880,8 +880,10 @@ def resunit_fusable(x: Tensor, g_sc: ConvGeom, g1: ConvGeom, g3: ConvGeom) -> bo
             and (g3.cin, g3.cout, g3.k) == (c // 2, c, 1))
 
 
-def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: Tensor, b3_f: Tensor, b3_b: Tensor, want_t: bool):
-    """(y, ELU(hidden) or None) of one residual unit in one launch (ga_resunit_fwd)."""
+def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: Tensor, b3_f: Tensor, b3_b: Tensor, want_t: bool, last=None):
+    """(y, ELU(hidden) or None) of one residual unit in one launch (ga_resunit_fwd).
+    last = (forward pack [1][7][32], bias) of the decoder's closing conv: the tail form -- returns (wav [B, L, 1] fp32, None)
+    and neither y nor the hidden tensor exists (callers that need no gradient)."""
     L.require_cuda(x, sc_f, b1_f, b3_f)
     B, lin, c = x.shape
     assert x.is_contiguous() and x.dtype == torch.bfloat16
@@ -889,10 +891,19 @@ def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: T
         assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.numel() >= n
     for b_, n in ((sc_b, c), (b1_b, c // 2), (b3_b, c)):
         assert b_.dtype == torch.float32 and b_.numel() == n
-    y = torch.empty_like(x)
-    t = torch.empty((B, lin, c // 2), device=x.device, dtype=x.dtype) if want_t else None
     p = L.ResunitParams()
-    _fill(p, x=x.data_ptr(), y=y.data_ptr(), t_act=L.ptr(t), w_sc=sc_f.data_ptr(), b_sc=sc_b.data_ptr(), w1=b1_f.data_ptr(),
+    if last is not None:
+        assert not want_t and c == 32 and lin >= 13
+        w_last, b_last = last
+        assert w_last.is_contiguous() and w_last.dtype == torch.bfloat16 and w_last.numel() >= 7 * 32 and b_last.dtype == torch.float32
+        y = torch.empty((B, lin, 1), device=x.device, dtype=torch.float32)
+        t = None
+        _fill(p, w_last=w_last.data_ptr(), b_last=b_last.data_ptr(), wav=y.data_ptr())
+    else:
+        y = torch.empty_like(x)
+        t = torch.empty((B, lin, c // 2), device=x.device, dtype=x.dtype) if want_t else None
+        _fill(p, y=y.data_ptr(), t_act=L.ptr(t))
+    _fill(p, x=x.data_ptr(), w_sc=sc_f.data_ptr(), b_sc=sc_b.data_ptr(), w1=b1_f.data_ptr(),
           b1=b1_b.data_ptr(), w3=b3_f.data_ptr(), b3=b3_b.data_ptr(), B=B, L=lin, C=c)
     if PROFILE is None:
         L.check(L.lib().ga_resunit_fwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_fwd")
@@ -901,8 +912,8 @@ def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: T
     e0.record()
     L.check(L.lib().ga_resunit_fwd(C.byref(p), L.dt(x), L.stream()), "ga_resunit_fwd")
     e1.record()
-    flops = 2.0 * B * lin * (c * c + 3 * c * (c // 2) + (c // 2) * c)
-    PROFILE.append((L.KERNEL_RESUNIT, flops, e0, e1, (B, c, c, 3, lin, 1, 1, L.ACT_ELU), flops))
+    flops = 2.0 * B * lin * (c * c + 3 * c * (c // 2) + (c // 2) * c + (7 * c if last is not None else 0))
+    PROFILE.append((L.KERNEL_RESUNIT, flops, e0, e1, (B, c, c if last is None else 1, 3, lin, 1, 1, L.ACT_ELU), flops))
     return y, t
 
 

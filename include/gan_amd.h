@@ -186,6 +186,14 @@ typedef struct ga_resunit_params {
     const void* w3;
     const float* b3;
     int B, L, C;
+    /* tail form (C == 32, L >= 13, no gradient wanted): wav != NULL makes the call ALSO run the decoder's closing layers on
+     * the unit's output -- wav[b][n] = b_last + sum_{j<7, c<32} w_last[j][c] * ELU(y)[b][n - 6 + j][c], reflect-left padded
+     * (modeling_encodec.py: the decoder's last nn.ELU + EncodecConv1d(32, 1, 7)) -- and write only that: [B][L] fp32; y and
+     * t_act must then be NULL.  w_last is the layer's GA_PACK_CONV_FWD pack [1][7][32]; the result equals
+     * ga_resunit_fwd followed by ga_conv (pre_act ELU, out_f32) to the last bit. */
+    const void* w_last;
+    const float* b_last;
+    float* wav;
 } ga_resunit_params;
 int ga_resunit_fwd(const ga_resunit_params* h_params, int dtype, ga_stream_t stream);
 /* The same unit's input gradient as one pass (autograd of the call above, reached from loss_g.backward(),

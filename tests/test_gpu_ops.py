@@ -1076,6 +1076,60 @@ def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c
         # closer to the fp32 result than the three-launch form (one rounding less): not asserted, both are inside the bf16 bound
 
 
+@pytest.mark.parametrize("lin,B", [(13, 2), (130, 3), (500, 1), (4173, 2), (120000, 2)])
+def test_no_gradient_unit_and_closing_conv_in_one_launch_match_separate_launches(lin, B):
+    """ga_resunit_fwd's tail form (the last residual unit + the decoder's closing ELU + conv 32 -> 1 k7 in one launch, for
+    callers that want no gradient: the unit's output never leaves the chip) against ga_resunit_fwd followed by the closing conv's
+    own ga_conv launch: the same bits where that launch runs conv_swin1_kernel (same rounding points, same MFMA chains: the
+    120000-sample case, with a ragged last tile), 1e-5 where short launches take thin.hip's vector-ALU kernel (another fp32
+    summation order); and against torch fp32.  13 is the shortest length (reflect rows 1..6 inside the first tile)."""
+    torch.manual_seed(lin)
+    c = 32
+    geoms = {"sc": ConvGeom("cconv", c, c, 1), "b1": ConvGeom("cconv", c, c // 2, 3), "b3": ConvGeom("cconv", c // 2, c, 1),
+             "last": ConvGeom("cconv", c, 1, 7)}
+    ws = {n: (torch.randn(g.cout, g.cin, g.k) * (1.5 / (g.cin * g.k) ** 0.5)).bfloat16().float() for n, g in geoms.items()}
+    bs = {n: torch.randn(g.cout) * 0.1 for n, g in geoms.items()}
+    pk = {n: ops.pack_frozen(g, ws[n].to(DEV), None, torch.bfloat16)[0] for n, g in geoms.items()}
+    bd = {n: b.to(DEV) for n, b in bs.items()}
+    x = torch.randn(B, lin, c).bfloat16()
+    xd = x.to(DEV)
+    args = (xd, pk["sc"], bd["sc"], pk["b1"], bd["b1"], pk["b3"], bd["b3"])
+    wav1, none = ops.resunit_forward(*args, want_t=False, last=(pk["last"], bd["last"]))
+    y, _ = ops.resunit_forward(*args, want_t=False)
+    wav2 = ops.conv_forward(geoms["last"], y, pk["last"], bd["last"], pre_act=L.ACT_ELU, out_f32=True)
+    assert none is None and wav1.shape == (B, lin, 1) and wav1.dtype == torch.float32
+    if B * lin >= 2 ** 17:
+        assert torch.equal(wav1, wav2)
+    close(wav1, wav2.cpu(), 1e-5, "tail form vs unit + closing conv")
+    if lin <= 5000:
+        xr = x.float().permute(0, 2, 1)
+        t = _ref_conv(geoms["b1"], xr, ws["b1"], bs["b1"], L.ACT_ELU, 0)
+        yr = _ref_conv(geoms["sc"], xr, ws["sc"], bs["sc"], 0, 0) + _ref_conv(geoms["b3"], t, ws["b3"], bs["b3"], L.ACT_ELU, 0)
+        wr = _ref_conv(geoms["last"], yr, ws["last"], bs["last"], L.ACT_ELU, 0)
+        close(wav1, wr.permute(0, 2, 1), TOL[torch.bfloat16], "tail form vs torch fp32")
+
+
+@pytest.mark.parametrize("T,B", [(1, 2), (9, 3), (375, 2)])
+def test_decoder_without_gradient_uses_the_tail_form_and_matches(T, B):
+    """SeanetDecoder under no_grad ends with the one-launch tail; same waveform as with it switched off and as the gradient path."""
+    from gan_amd.lab3_codec_bridge import SeanetDecoder
+    torch.manual_seed(T)
+    dec = SeanetDecoder(precision="bf16").to(DEV)
+    for p_ in dec.parameters():
+        p_.data.normal_(0.0, 0.12)
+    dec.invalidate_packs()
+    q = torch.randn(B, 128, T, device=DEV)
+    outs = []
+    for tail in (True, False):
+        dec.fuse_tail = tail
+        with torch.no_grad():
+            outs.append(dec(q).float().cpu())
+    assert outs[0].shape == (B, 1, T * 320)
+    close(outs[0], outs[1], 1e-5, "decoder with / without the tail form")
+    wav = dec(q.clone().requires_grad_(True))
+    assert torch.equal(wav.detach().float().cpu(), outs[1])
+
+
 def test_pack_cache_is_released_with_its_optimizer():
     """Packed weights are cached per optimizer epoch; when the FusedAdamW that owns the parameter buffer is dropped (one per
     train_codec_stage call), its packs and its epoch range go with it instead of staying resident for the life of the process."""
