@@ -40,7 +40,7 @@ class ConvParams(C.Structure):
         ("pad_mode", C.c_int), ("pre_act", C.c_int), ("post_act", C.c_int), ("dact_mode", C.c_int),
         ("accumulate", C.c_int), ("nphase", C.c_int),
         ("phase_off0", C.c_int * GA_MAX_PHASE), ("out_f32", C.c_int), ("ksplit", C.c_int), ("ws", C.c_void_p),
-        ("y_batch_elems", C.c_int), ("res_mode", C.c_int), ("res_coef", C.c_float), ("res_coef_dev", C.c_void_p),
+        ("y_batch_elems", C.c_int), ("res_mode", C.c_int), ("res_coef", C.c_float), ("res_coef_dev", C.c_void_p), ("y2", C.c_void_p),
     ]
 
 

@@ -51,8 +51,10 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_swin_wanted(p) ? ga_conv_swin_impl(p, s) : ga_conv_stream_impl(p, s);
     // single-output-channel thin layers, long launches: the streaming-window kernel's dot-product form
-    if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && p.res_mode == GA_RES_ADD && ga_conv_swin_wanted(p))
+    if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && p.res_mode == GA_RES_ADD && !p.y2 && ga_conv_swin_wanted(p))
         return ga_conv_swin_impl(p, s);
+    if (p.y2)  // second (ELU) output: the gathered-GEMM kernel's epilogue only
+        return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && p.ksplit <= 1 && !p.out_f32) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
     if (p.res_mode == GA_RES_ADD_THEN_ACT)  // activation after the residual sum: the gathered-GEMM kernel's epilogue only
         return (can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && p.res && p.ksplit <= 1) ? ga_conv_gemm_impl(p, s) : GA_ERR_ARG;
     if (p.res_mode != GA_RES_ADD) {  // only the gathered-GEMM kernel's epilogue forms the feature-matching term
@@ -79,7 +81,7 @@ int ga_conv(const ga_conv_params* hp, int dtype, int impl, hipStream_t s) {
 }
 
 int ga_conv_suggest_ksplit(const ga_conv_params* hp, int dtype, int impl) {
-    if (!hp || dtype != GA_DTYPE_BF16 || (impl != GA_IMPL_AUTO && impl != GA_IMPL_MFMA)) return 1;
+    if (!hp || dtype != GA_DTYPE_BF16 || (impl != GA_IMPL_AUTO && impl != GA_IMPL_MFMA) || hp->y2) return 1;
     return ga_conv_gemm_suggest_ksplit(*hp);
 }
 
@@ -103,7 +105,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? GA_KERNEL_CONV_WIN : -1;
     if (impl == GA_IMPL_MFMA_STREAM) return (dtype == GA_DTYPE_BF16 && ga_conv_stream_supported(p)) ? GA_KERNEL_STREAM : -1;
     if (impl == GA_IMPL_MFMA_STREAMWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_swin_supported(p)) ? GA_KERNEL_STREAM_WIN : -1;
-    if (p.res_mode != GA_RES_ADD) {  // ga_conv: gathered-GEMM kernel or nothing
+    if (p.res_mode != GA_RES_ADD || p.y2) {  // ga_conv: gathered-GEMM kernel or nothing
         if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
         if (ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
         if (ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;

@@ -420,6 +420,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
                 *(bf16x8*)(y + o) = ov;
+                if (p.y2) {  // ELU of the value just stored (what a separate pass over y would read)
+                    bf16x8 ev;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ev[i] = (__bf16)elu_bf16_grade((float)ov[i]);
+                    *(bf16x8*)((bf16_t*)p.y2 + o) = ev;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -624,6 +630,7 @@ int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.res_mode == GA_RES_ADD_THEN_ACT && (!p.res || p.ksplit > 1 || p.dact_mode)) return GA_ERR_ARG;
+    if (p.y2 && (p.ksplit > 1 || p.out_f32 || ((uintptr_t)p.y2 & 15))) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
     if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
     if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)

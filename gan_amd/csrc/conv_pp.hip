@@ -381,7 +381,7 @@ int ga_conv_gemm_supported(const ConvParams& p);
 
 // The ping-pong kernel takes what the gathered-GEMM kernel takes, single phase, with 32-bit element offsets.
 int ga_conv_pp_supported(const ConvParams& p) {
-    if (!ga_conv_gemm_supported(p) || p.nphase != 1 || p.res_mode == GA_RES_ADD_THEN_ACT) return 0;
+    if (!ga_conv_gemm_supported(p) || p.nphase != 1 || p.res_mode == GA_RES_ADD_THEN_ACT || p.y2) return 0;
     if ((long)p.B * p.Lin * p.Cin >= (1L << 31) - (1L << 24) || (long)p.M * p.J * p.Cin >= (1L << 31) - (1L << 24)) return 0;
     if ((long)(labs((long)p.off0) + (long)p.J * p.tap_step + 2) * p.Cin >= (1L << 24)) return 0;  // window offsets stay far from overflow
     return 1;

@@ -277,7 +277,7 @@ static int stream_cin1_ok(const ConvParams& p) {
 }
 
 int ga_conv_stream_supported(const ConvParams& p) {
-    if (p.res_mode != GA_RES_ADD) return 0;
+    if (p.res_mode != GA_RES_ADD || p.y2) return 0;
     if (p.pre_act != GA_ACT_NONE && p.pre_act != GA_ACT_ELU) return 0;
     if (p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
     if (p.dact_mode != GA_DACT_NONE && p.dact_mode != GA_DACT_ELU_FROM_IN && p.dact_mode != GA_DACT_LRELU_FROM_OUT &&

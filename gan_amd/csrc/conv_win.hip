@@ -247,7 +247,7 @@ int ga_conv_gemm_supported(const ConvParams& p);
 // 1: Cin = 32 / stride 4 form, 2: Cin = 64 / stride 1 form, 0: not a window-kernel problem
 int ga_conv_win_supported(const ConvParams& p) {
     if (!ga_conv_gemm_supported(p) || p.nphase != 1 || p.pad_mode != 0 || p.tap_step != 1 || p.out_f32 || p.ksplit > 1) return 0;
-    if (p.res_mode == GA_RES_ADD_THEN_ACT) return 0;
+    if (p.res_mode == GA_RES_ADD_THEN_ACT || p.y2) return 0;
     if ((long)p.B * p.Lin * p.Cin >= (1L << 31)) return 0;
     if (p.Cin == 32 && p.in_stride == 4 && p.J <= 44 && p.M <= 64 && p.M % 8 == 0) return 1;
     if (p.Cin == 64 && p.in_stride == 1 && p.J <= 12 && p.M >= 96 && p.M % 8 == 0) return 2;

@@ -86,6 +86,7 @@ class SeanetDecoder(nn.Module):
         self.use_library_lstm = False  # True: torch's LSTM op (MIOpen) instead of the gan_amd step kernels (A/B checks)
         self.fuse_resblock = os.environ.get("GA_FUSE_RESBLOCK", "1") != "0"  # False: a residual unit as three autograd nodes (A/B checks)
         self.fuse_elu = os.environ.get("GA_FUSE_ELU", "1") != "0"            # False: every ELU in front of a wide conv is a pass of its own
+        self.fuse_elu2 = os.environ.get("GA_FUSE_ELU2", "1") != "0"          # False: no second (ELU) output from the transposed convs' epilogues
         self.fuse_tail = os.environ.get("GA_FUSE_TAIL", "1") != "0"          # False: no-gradient decodes end with separate unit / last-conv launches
         self.ratios = tuple(int(r) for r in ratios)
         c = (2 ** len(self.ratios)) * num_filters
@@ -133,9 +134,9 @@ class SeanetDecoder(nn.Module):
             self._packs[key] = ops.pack_frozen(layer.geom, layer.conv.v.data, layer.conv.g.data, dtype)
         return self._packs[key]
 
-    def _conv(self, name: str, layer: _ConvLayer, x, dtype, pre_act=L.ACT_NONE, res=None, out_f32=False):
+    def _conv(self, name: str, layer: _ConvLayer, x, dtype, pre_act=L.ACT_NONE, res=None, out_f32=False, also_elu=False):
         wp_f, wp_d = self._pack(name, layer, dtype)
-        return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act, out_f32)
+        return ops.ConvFrozen.apply(x, res, wp_f, wp_d, layer.conv.bias.data, layer.geom, pre_act, out_f32, also_elu)
 
     def forward(self, q_bct: torch.Tensor, n_grad: Optional[int] = None):
         """q [B, 128, T] -> wav [B, 1, T*prod(ratios)].
@@ -166,6 +167,7 @@ class SeanetDecoder(nn.Module):
 
     def _tail(self, h: torch.Tensor, dtype, plan) -> torch.Tensor:
         elu_done = False  # h holds ELU(h): written by the residual unit in front (ops.ResBlockFrozen, elu_out)
+        h_elu = None      # ELU(h) next to h: written by the transposed conv in front (ga_conv_params.y2) for the unit's first conv
         for pos, (kind, name) in enumerate(plan):
             layer = getattr(self.layers, name)
             if kind == "conv":
@@ -184,7 +186,18 @@ class SeanetDecoder(nn.Module):
                         self._packs[key] = ops.prepare_lstm_weights(layer.lstm, dtype)
                     h = ops.LstmSkip.apply(h, self._packs[key])
             elif kind == "elu_convt":
-                h = self._conv(name, layer, h, dtype, pre_act=ops.ACT_ELU_DONE if elu_done else L.ACT_ELU)
+                nxt = plan[pos + 1] if pos + 1 < len(plan) else None
+                two = False
+                if dtype == torch.bfloat16 and self.fuse_resblock and self.fuse_elu and self.fuse_elu2 and nxt is not None and nxt[0] == "resblock":
+                    # the unit behind reads this layer's output raw (shortcut) and through ELU (first conv): where that ELU would be
+                    # a pass of its own (wide units on the gathered-GEMM kernel), this layer's epilogue writes it as well
+                    unit = getattr(self.layers, nxt[1])
+                    b1g = getattr(unit.block, "1").geom
+                    meta = torch.empty((h.shape[0], layer.geom.out_len(h.shape[1]), b1g.cin), dtype=h.dtype, device="meta")
+                    two = (not ops.resunit_fusable(meta, unit.shortcut.geom, b1g, getattr(unit.block, "3").geom)
+                           and ops.elu_needs_a_pass(b1g, meta) and ops.conv_second_output_ok(layer.geom, h))
+                out = self._conv(name, layer, h, dtype, pre_act=ops.ACT_ELU_DONE if elu_done else L.ACT_ELU, also_elu=two)
+                h, h_elu = out if two else (out, None)
                 elu_done = False
             elif kind == "resblock":
                 b1, b3 = getattr(layer.block, "1"), getattr(layer.block, "3")
@@ -210,8 +223,9 @@ class SeanetDecoder(nn.Module):
                     h = ops.ResBlockFrozen.apply(
                         h, *self._pack(name + ".sc", layer.shortcut, dtype), layer.shortcut.conv.bias.data, layer.shortcut.geom,
                         *self._pack(name + ".b1", b1, dtype), b1.conv.bias.data, b1.geom,
-                        *self._pack(name + ".b3", b3, dtype), b3.conv.bias.data, b3.geom, elu_mid, elu_out)
+                        *self._pack(name + ".b3", b3, dtype), b3.conv.bias.data, b3.geom, elu_mid, elu_out, h_elu)
                     elu_done = elu_out
+                    h_elu = None
                 else:
                     sc = self._conv(name + ".sc", layer.shortcut, h, dtype)
                     t = self._conv(name + ".b1", b1, h, dtype, pre_act=L.ACT_ELU)

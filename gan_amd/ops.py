@@ -242,8 +242,9 @@ def _cin1_padded(g: ConvGeom, x: Tensor):
 
 
 def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre_act=0, post_act=0, res=None,
-                 out_f32: bool = False, act_after_res: bool = False) -> Tensor:
-    """act_after_res: y = post_act(conv + bias + res) instead of post_act(conv + bias) + res (GA_RES_ADD_THEN_ACT)."""
+                 out_f32: bool = False, act_after_res: bool = False, elu_out2: bool = False):
+    """act_after_res: y = post_act(conv + bias + res) instead of post_act(conv + bias) + res (GA_RES_ADD_THEN_ACT).
+    elu_out2: returns (y, ELU(y)), the second written by the same epilogue (ga_conv_params.y2; check conv_second_output_ok)."""
     B, lin, cin = x.shape
     assert cin == g.cin, (cin, g.cin)
     p = fwd_params(g, B, lin)
@@ -253,13 +254,29 @@ def conv_forward(g: ConvGeom, x: Tensor, wp: Tensor, bias: Optional[Tensor], pre
         p.res_mode = L.RES_ADD_THEN_ACT
     p.out_f32 = 1 if (out_f32 and x.dtype == torch.bfloat16) else 0
     y = torch.empty((B, p.LoutTot, g.cout), device=x.device, dtype=torch.float32 if p.out_f32 else x.dtype)
-    if not pre_act and res is None and not p.out_f32:
+    y2 = None
+    if elu_out2:
+        assert x.dtype == torch.bfloat16 and not p.out_f32
+        y2 = torch.empty_like(y)
+        p.y2 = y2.data_ptr()
+    if not pre_act and res is None and not p.out_f32 and y2 is None:
         xp, front = _cin1_padded(g, x)
         if xp is not None:  # the same problem on the zero-padded copy: no row is ever out of range
             p.Lin, p.off0 = xp.shape[1], p.off0 + front
             x = xp
     _launch_conv(p, x, wp, y, bias=bias, res=res, impl=_IMPL)
-    return y
+    return y if y2 is None else (y, y2)
+
+
+def conv_second_output_ok(g: ConvGeom, x: Tensor) -> bool:
+    """True when ga_conv can write ELU(y) next to y for this forward (the gathered-GEMM kernel's epilogue, ga_conv_params.y2)."""
+    if x.dtype != torch.bfloat16 or _IMPL not in (L.IMPL_AUTO, L.IMPL_MFMA):
+        return False
+    p = fwd_params(g, x.shape[0], x.shape[1])
+    p.x = p.w = p.y = p.y2 = 256  # alignment checks only: nothing is dereferenced
+    if MERGE_PHASES:
+        p, _ = _fold_phases(p, x, None)
+    return L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), _IMPL) in (7, 8, 9)
 
 
 def conv_dgrad(g: ConvGeom, gy: Tensor, wp_d: Tensor, lin: int, dact_mode=0, dact_src=None, res=None, fm_coef=None) -> Tensor:
@@ -857,15 +874,17 @@ ACT_ELU_DONE = -2
 
 
 def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int, res=None, out_f32: bool = False, post_act: int = 0,
-                    act_after_res: bool = False) -> Tensor:
+                    act_after_res: bool = False, elu_out2: bool = False):
     res = None if res is None else res.contiguous()
     if pre_act == ACT_ELU_DONE:
         pre_act = L.ACT_NONE
     if pre_act and x.dtype == torch.bfloat16 and geom.cout >= 16 and (post_act or not _streams_with_pre_act(geom, x, pre_act)):
         # bf16: materialise act(x) once (one streaming pass) so the conv takes the direct-to-LDS GEMM kernel,
         # which cannot transform its operand in flight (the thin layers' streaming kernels can: no copy there)
-        return conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res)
-    return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res)
+        return conv_forward(geom, act_fwd(x, pre_act), wp_f, bias, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res,
+                            elu_out2=elu_out2)
+    return conv_forward(geom, x, wp_f, bias, pre_act=pre_act, post_act=post_act, res=res, out_f32=out_f32, act_after_res=act_after_res,
+                        elu_out2=elu_out2)
 
 
 FUSE_RESUNIT = os.environ.get("GA_FUSE_RESUNIT", "1") != "0"  # False: a thin residual unit's forward as three ga_conv launches (A/B checks)
@@ -958,7 +977,8 @@ class ResBlockFrozen(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, sc_f, sc_d, sc_b, g_sc: ConvGeom, b1_f, b1_d, b1_b, g1: ConvGeom, b3_f, b3_d, b3_b, g3: ConvGeom,
-                elu_mid: bool = False, elu_out: bool = False):
+                elu_mid: bool = False, elu_out: bool = False, x_elu=None):
+        """x_elu: ELU(x), already written by x's producer (ConvFrozen also_elu): the first conv reads it instead of a pass over x."""
         x = x.contiguous()
         if not elu_out and resunit_fusable(x, g_sc, g1, g3):
             # the thin units (32 / 64 channels): one pass over x instead of three launches; the hidden tensor is kept, as ELU(t),
@@ -969,7 +989,10 @@ class ResBlockFrozen(torch.autograd.Function):
             return y
         ctx.one_launch = False
         sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
-        t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
+        if x_elu is not None:
+            t = _frozen_forward(g1, x_elu.contiguous(), b1_f, b1_b, ACT_ELU_DONE, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
+        else:
+            t = _frozen_forward(g1, x, b1_f, b1_b, L.ACT_ELU, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)
         y = _frozen_forward(g3, t, b3_f, b3_b, ACT_ELU_DONE if elu_mid else L.ACT_ELU, res=sc,
                             post_act=L.ACT_ELU if elu_out else L.ACT_NONE, act_after_res=elu_out)
         ctx.geoms, ctx.elu_mid = (g_sc, g1, g3), elu_mid
@@ -984,11 +1007,11 @@ class ResBlockFrozen(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous().to(x.dtype)
             if ctx.one_launch and FUSE_RESUNIT_BWD:
-                return (resunit_backward(gy, t, x, sc_d, b1_d, b3_d),) + (None,) * 14
+                return (resunit_backward(gy, t, x, sc_d, b1_d, b3_d),) + (None,) * 15
             gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_OUT if ctx.elu_mid else L.DACT_ELU_FROM_IN, dact_src=t)
             gb = conv_dgrad(g1, gt, b1_d, x.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)
             gx = conv_dgrad(g_sc, gy, sc_d, x.shape[1], res=gb)
-        return (gx,) + (None,) * 14
+        return (gx,) + (None,) * 15
 
 
 class ConvFrozen(torch.autograd.Function):
@@ -996,17 +1019,20 @@ class ConvFrozen(torch.autograd.Function):
     dx = dgrad(gy) * pre_act'(x) (+ the residual branch's gradient when given through `gres_into`)."""
 
     @staticmethod
-    def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False):
+    def forward(ctx, x, res, wp_f, wp_d, bias, geom: ConvGeom, pre_act: int, out_f32: bool = False, also_elu: bool = False):
+        """also_elu: returns (y, ELU(y)); the second output carries no gradient (its consumer differentiates through y)."""
         x = x.contiguous()
-        y = _frozen_forward(geom, x, wp_f, bias, pre_act, res, out_f32)
+        y = _frozen_forward(geom, x, wp_f, bias, pre_act, res, out_f32, elu_out2=also_elu)
         ctx.geom, ctx.pre_act = geom, pre_act
         ctx.x_dtype = x.dtype
         ctx.save_for_backward(x if pre_act else None, wp_d)
         ctx.lin = x.shape[1]
+        if also_elu:
+            ctx.mark_non_differentiable(y[1])
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gy2=None):
         x, wp_d = ctx.saved_tensors
         gy = gy.contiguous().to(ctx.x_dtype)
         gx = None
@@ -1020,7 +1046,7 @@ class ConvFrozen(torch.autograd.Function):
             else:
                 raise NotImplementedError
         gres = gy if ctx.needs_input_grad[1] else None
-        return gx, gres, None, None, None, None, None, None
+        return gx, gres, None, None, None, None, None, None, None
 
 
 # ================================================================================================

@@ -105,6 +105,10 @@ typedef struct ga_conv_params {
                     the transposed conv behind it (modeling_encodec.py:340-343 then :268) with no pass of its own */
     float res_coef;
     const float* res_coef_dev; /* device scalar (the loss term's upstream gradient) */
+    void* y2;       /* NULL, or (bf16, gathered-GEMM kernel only, no split-K, not with out_f32) a second output of y's shape that
+                    receives ELU(y), taken from the rounded value y holds: a layer whose output is consumed both raw (a residual
+                    unit's shortcut, modeling_encodec.py:333-336) and through ELU (the unit's first conv, :326-328) hands the
+                    ELU over with no pass of its own */
 } ga_conv_params;
 #define GA_RES_ADD 0
 #define GA_RES_FM_SIGN 1

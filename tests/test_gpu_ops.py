@@ -1130,6 +1130,40 @@ def test_decoder_without_gradient_uses_the_tail_form_and_matches(T, B):
     assert torch.equal(wav.detach().float().cpu(), outs[1])
 
 
+def test_second_elu_output_of_the_gathered_gemm_epilogue():
+    """ga_conv_params.y2: the decoder's transposed convs 512->256 (k16 s8) and 256->128 (k10 s5) write ELU(y) next to y for the
+    residual unit behind them (shortcut reads y, first conv reads ELU(y)): y unchanged to the last bit, y2 = ELU of the stored
+    bf16 value to one bf16 step (exp2-based ELU); the decoder's waveform and input gradient with the second output on / off."""
+    torch.manual_seed(77)
+    for g, lin, B in ((ConvGeom("convt", 256, 128, 10, 5), 601, 3), (ConvGeom("convt", 512, 256, 16, 8), 75, 2), (ConvGeom("cconv", 128, 128, 1), 999, 2)):
+        w = torch.randn(*g.wdims) * (1.5 / (g.cin * (g.k if g.kind != "convt" else 2)) ** 0.5)
+        b = (torch.randn(g.cout) * 0.3).to(DEV)
+        wp = ops.pack_frozen(g, w.to(DEV), None, torch.bfloat16)[0]
+        x = torch.randn(B, lin, g.cin, device=DEV).bfloat16()
+        assert ops.conv_second_output_ok(g, x)
+        y0 = ops.conv_forward(g, x, wp, b)
+        y, y2 = ops.conv_forward(g, x, wp, b, elu_out2=True)
+        assert torch.equal(y, y0) and y2.shape == y.shape and y2.dtype == torch.bfloat16
+        ref = F.elu(y.float()).bfloat16().float().cpu()
+        assert ((y2.float().cpu() - ref).abs() <= 2.0 ** -7 * ref.abs().clamp_min(1e-3)).all()
+    assert not ops.conv_second_output_ok(ConvGeom("cconv", 128, 128, 1), torch.empty(2, 99, 128, device=DEV))  # fp32: no such epilogue
+    from gan_amd.lab3_codec_bridge import SeanetDecoder
+    dec = SeanetDecoder(precision="bf16").to(DEV)
+    for p_ in dec.parameters():
+        p_.data.normal_(0.0, 0.05)
+    dec.invalidate_packs()
+    q = torch.randn(2, 128, 9, device=DEV)
+    outs = {}
+    for two in (False, True):
+        dec.fuse_elu2 = two
+        qq = q.clone().requires_grad_(True)
+        wav = dec(qq)
+        gq, = torch.autograd.grad(wav.float().square().sum(), qq)
+        outs[two] = (wav.detach().float().cpu(), gq.float().cpu())
+    close(outs[True][0], outs[False][0], 1e-2, "second ELU output, wav")
+    close(outs[True][1], outs[False][1], 2e-2, "second ELU output, dq")
+
+
 def test_pack_cache_is_released_with_its_optimizer():
     """Packed weights are cached per optimizer epoch; when the FusedAdamW that owns the parameter buffer is dropped (one per
     train_codec_stage call), its packs and its epoch range go with it instead of staying resident for the life of the process."""

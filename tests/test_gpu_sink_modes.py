@@ -42,12 +42,14 @@ def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
         results.append((og.flat_p.clone(), od.flat_p.clone(), float(out["loss_g"]), float(out["loss_d"]), float(out["loss_ms"]),
                         og.flat_g.clone(), od.flat_g.clone()))
     a, b = results
-    assert a[2] == pytest.approx(b[2], rel=1e-6) and a[3] == pytest.approx(b[3], rel=1e-6) and a[4] == pytest.approx(b[4], rel=1e-6)
+    # (loss sums and weight gradients are accumulated with fp32 atomics, whose order changes from run to run: the bounds below are
+    # that noise with a margin -- at 1e-6 / 2e-6 this test failed about one run in ten of the full suite and never alone)
+    assert a[2] == pytest.approx(b[2], rel=1e-5) and a[3] == pytest.approx(b[3], rel=1e-5) and a[4] == pytest.approx(b[4], rel=1e-5)
     # the gradient buffers (what the two paths differ in) agree to fp32 summation order ...
     for ga, gb, name in ((a[5], b[5], "G grad"), (a[6], b[6], "D grad")):
         assert float(gb.abs().max()) > 0
         err = float((ga - gb).abs().max() / gb.abs().max())
-        assert err <= 2e-6, (name, err)
+        assert err <= 1e-5, (name, err)
     # ... and so do the parameters after the step, up to what AdamW's first step (lr * g / (|g| + eps)) makes of that noise
     for pa, pb, name in ((a[0], b[0], "G"), (a[1], b[1], "D")):
         err = float((pa - pb).abs().max() / pb.abs().max())
