@@ -43,7 +43,7 @@ def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
                         og.flat_g.clone(), od.flat_g.clone()))
     a, b = results
     # (loss sums and weight gradients are accumulated with fp32 atomics, whose order changes from run to run: the bounds below are
-    # that noise with a margin -- at 1e-6 / 2e-6 this test failed about one run in ten of the full suite and never alone)
+    # that noise with a margin -- at 1e-6 / 2e-6 this test failed once inside a full-suite run and passed alone and on the re-run)
     assert a[2] == pytest.approx(b[2], rel=1e-5) and a[3] == pytest.approx(b[3], rel=1e-5) and a[4] == pytest.approx(b[4], rel=1e-5)
     # the gradient buffers (what the two paths differ in) agree to fp32 summation order ...
     for ga, gb, name in ((a[5], b[5], "G grad"), (a[6], b[6], "D grad")):
