@@ -105,6 +105,8 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (impl == GA_IMPL_MFMA_LDSWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_win_supported(p)) ? GA_KERNEL_CONV_WIN : -1;
     if (impl == GA_IMPL_MFMA_STREAM) return (dtype == GA_DTYPE_BF16 && ga_conv_stream_supported(p)) ? GA_KERNEL_STREAM : -1;
     if (impl == GA_IMPL_MFMA_STREAMWIN) return (dtype == GA_DTYPE_BF16 && ga_conv_swin_supported(p)) ? GA_KERNEL_STREAM_WIN : -1;
+    if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && p.res_mode == GA_RES_ADD_THEN_ACT && ga_conv_stream_supported(p))
+        return GA_KERNEL_STREAM;  // (as ga_conv: the streaming kernels are asked first)
     if (p.res_mode != GA_RES_ADD || p.y2) {  // ga_conv: gathered-GEMM kernel or nothing
         if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
         if (ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;

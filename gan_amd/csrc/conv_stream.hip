@@ -17,6 +17,7 @@
 // Epilogue variants are compile-time (SIDE: none / residual / derivative source) so that the loop stays small and
 // branch-free; other combinations (accumulate, fp32 output, residual AND derivative) stay with conv_gemm.hip.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -80,7 +81,10 @@ __device__ __forceinline__ void divmod_small(int n, int L, float rcpL, int& q, i
 // 16-byte piece here, so the caller hands in a zero-padded copy of x in which every window is in range (checked on the host).
 template <int MT, int KS, int NT, bool PRE_ELU, int SIDE, bool CIN1 = false>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot, int ng, float rcpL) {
-    constexpr int WMR = MT * 32;
+    constexpr int EM = MT > 2 ? 2 : MT;  // m-tiles per epilogue round (the stage holds at most 64 channels per row)
+    constexpr int ER = MT / EM;          // epilogue rounds: 2 for the 128-channel form
+    static_assert(MT % EM == 0, "rounds");
+    constexpr int WMR = EM * 32;
     constexpr int EPF = WMR + 4;
     constexpr int LPR = WMR / 8;    // lanes per staged row (8 output channels each)
     constexpr int RPP = 64 / LPR;   // rows per pass
@@ -133,11 +137,18 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
     const size_t item_elems = p.y_batch_elems > 0 ? (size_t)p.y_batch_elems : (size_t)p.LoutTot * p.M;
     const float slope = p.post_act == GA_ACT_LRELU ? 0.2f : 1.f;
     const int dmode = p.dact_mode;  // (uniform: the compiler hoists the choice out of the element loop)
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias && m0 < p.M) {
-        const float4 b0 = *(const float4*)(p.bias + m0), b1 = *(const float4*)(p.bias + m0 + 4);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    const bool elu_after = p.res_mode == GA_RES_ADD_THEN_ACT;  // ELU(acc + bias + res)
+    float bv[ER][8];
+#pragma unroll
+    for (int er = 0; er < ER; ++er) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[er][i] = 0.f;
+        const int mm = er * WMR + m0;
+        if (p.bias && mm < p.M) {
+            const float4 b0 = *(const float4*)(p.bias + mm), b1 = *(const float4*)(p.bias + mm + 4);
+            bv[er][0] = b0.x; bv[er][1] = b0.y; bv[er][2] = b0.z; bv[er][3] = b0.w;
+            bv[er][4] = b1.x; bv[er][5] = b1.y; bv[er][6] = b1.z; bv[er][7] = b1.w;
+        }
     }
 
     // x fragments of group g (every load is issued; rows or k past the end read the zero page)
@@ -166,17 +177,18 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
     };
 
     // output element offset of this lane's 8 channels in pass ps of tile nt of group g (-1: nothing to write)
-    auto out_offset = [&](int g, int nt, int ps) __attribute__((always_inline)) -> long {
+    auto out_offset = [&](int g, int nt, int ps, int er) __attribute__((always_inline)) -> long {
         const int n = (g * NT + nt) * 32 + ps * RPP + erow;
         int b, tl;
         divmod_small(n, Lout, rcpL, b, tl);
         const int orow = (p.t0 + tl) * p.out_stride;
-        const size_t in_item = (size_t)orow * p.M + m0;
-        const bool ok = n < Ntot && m0 < p.M && orow >= 0 && orow < p.LoutTot && in_item + 8 <= item_elems;
+        const int mm = er * WMR + m0;
+        const size_t in_item = (size_t)orow * p.M + mm;
+        const bool ok = n < Ntot && mm < p.M && orow >= 0 && orow < p.LoutTot && in_item + 8 <= item_elems;
         return ok ? (long)((size_t)b * item_elems + in_item) : -1L;
     };
 
-    auto compute = [&](bf16x8 (&buf)[NT][KS], bf16x8 (&side)[NT][NPS], int g) __attribute__((always_inline)) {
+    auto compute = [&](bf16x8 (&buf)[NT][KS], bf16x8 (&side)[NT][ER][NPS], int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x16 acc[MT];
@@ -191,34 +203,40 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], xb, acc[mt], 0, 0, 0);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+          for (int er = 0; er < ER; ++er) {
+#pragma unroll
+            for (int me = 0; me < EM; ++me)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *(float4*)(stage + r * EPF + mt * 32 + 8 * q + 4 * h) =
-                        make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+                    *(float4*)(stage + r * EPF + me * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[er * EM + me][4 * q], acc[er * EM + me][4 * q + 1], acc[er * EM + me][4 * q + 2], acc[er * EM + me][4 * q + 3]);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
                 const int row = ps * RPP + erow;
-                const long o = out_offset(g, nt, ps);
+                const long o = out_offset(g, nt, ps, er);
                 float v[8];
                 *(float4*)&v[0] = *(const float4*)(stage + row * EPF + m0);
                 *(float4*)&v[4] = *(const float4*)(stage + row * EPF + m0 + 4);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    v[i] += bv[i];
+                    v[i] += bv[er][i];
                     v[i] = v[i] > 0.f ? v[i] : slope * v[i];
                 }
                 if (SIDE == SIDE_DACT) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float sv = (float)side[nt][ps][i];
+                        const float sv = (float)side[nt][er][ps][i];
                         v[i] *= sv > 0.f ? 1.f : (dmode == GA_DACT_ELU_FROM_IN ? __expf(sv) : dmode == GA_DACT_ELU_FROM_OUT ? sv + 1.f : 0.2f);
                     }
                 }
                 if (SIDE == SIDE_RES) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += (float)side[nt][ps][i];
+                    for (int i = 0; i < 8; ++i) v[i] += (float)side[nt][er][ps][i];
+                    if (elu_after) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = elu_bf16_grade(v[i]);
+                    }
                 }
                 bf16x8 ov;
 #pragma unroll
@@ -226,24 +244,27 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvParams p, int Ntot
                 if (o >= 0) *(bf16x8*)(y + o) = ov;
             }
             __builtin_amdgcn_wave_barrier();
+          }
         }
     };
 
-    auto load_side = [&](bf16x8 (&side)[NT][NPS], int g) __attribute__((always_inline)) {
+    auto load_side = [&](bf16x8 (&side)[NT][ER][NPS], int g) __attribute__((always_inline)) {
         if (SIDE == SIDE_NONE) return;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int ps = 0; ps < NPS; ++ps) {
-                const long o = out_offset(g, nt, ps);
-                side[nt][ps] = ldg_frag(sel_addr_s(o >= 0, (uintptr_t)(side_src + (o >= 0 ? o : 0)), zero));
-            }
+            for (int er = 0; er < ER; ++er)
+#pragma unroll
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const long o = out_offset(g, nt, ps, er);
+                    side[nt][er][ps] = ldg_frag(sel_addr_s(o >= 0, (uintptr_t)(side_src + (o >= 0 ? o : 0)), zero));
+                }
     };
 
     const int stride = gridDim.x * 4;
     int g = blockIdx.x * 4 + wid;
     if (g >= ng) return;
-    bf16x8 b0[NT][KS], b1[NT][KS], sd[NT][NPS];
+    bf16x8 b0[NT][KS], b1[NT][KS], sd[NT][ER][NPS];
     load(b0, g);
     while (true) {  // two groups per trip: the buffers swap roles by name, never by copy
         load_side(sd, g);
@@ -277,16 +298,28 @@ static int stream_cin1_ok(const ConvParams& p) {
 }
 
 int ga_conv_stream_supported(const ConvParams& p) {
-    if (p.res_mode != GA_RES_ADD || p.y2) return 0;
+    // ELU after the residual sum (a residual unit handing ELU(output) on): only what the unit's second conv looks like
+    const bool elu_after = p.res_mode == GA_RES_ADD_THEN_ACT;
+    if (elu_after ? !(p.res && p.post_act == GA_ACT_ELU && !p.dact_mode && !p.dact_src) : p.res_mode != GA_RES_ADD) return 0;
+    if (p.y2) return 0;
     if (p.pre_act != GA_ACT_NONE && p.pre_act != GA_ACT_ELU) return 0;
-    if (p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
+    if (!elu_after && p.post_act != GA_ACT_NONE && p.post_act != GA_ACT_LRELU) return 0;
     if (p.dact_mode != GA_DACT_NONE && p.dact_mode != GA_DACT_ELU_FROM_IN && p.dact_mode != GA_DACT_LRELU_FROM_OUT &&
         p.dact_mode != GA_DACT_ELU_FROM_OUT) return 0;
     if (p.dact_mode && !p.dact_src) return 0;
     if (p.accumulate || p.out_f32 || stream_side(p) < 0) return 0;
     if (p.pre_act == GA_ACT_ELU && p.dact_mode) return 0;  // (not instantiated: a forward fuses ELU, a data gradient its derivative)
     if (p.nphase != 1 || p.ksplit > 1) return 0;
-    if (p.M % 8 || p.M < 8 || p.M > 64 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if (p.M % 8 || p.M < 8 || p.M > 128 || p.tap_step < 0 || p.J < 1 || p.B < 1 || p.Lout < 0) return 0;
+    if (p.M > 64 && (p.Cin == 1 || (long)p.J * p.Cin > 64 || p.pre_act)) return 0;  // 128 channels: K <= 64 (64 weight registers)
+    if (p.M > 64 || elu_after) {
+        static int wide = -1;  // GA_STREAM_M128=0: these stay with the gathered-GEMM kernel (A/B checks)
+        if (wide < 0) {
+            const char* e = getenv("GA_STREAM_M128");
+            wide = e ? atoi(e) : 1;
+        }
+        if (!wide) return 0;
+    }
     if (p.Cin == 1) {
         if (!stream_cin1_ok(p)) return 0;
     } else if (p.Cin % 8 || p.Cin < 8) {
@@ -350,5 +383,9 @@ static int launch_stream_mt(const ConvParams& p, hipStream_t s) {
 int ga_conv_stream_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_stream_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
+    if (p.M > 64) {  // (K <= 64, no single-channel form: checked above)
+        const int ks = (p.J * p.Cin + 15) / 16;
+        return ks <= 1 ? launch_stream<4, 1, 2>(p, s) : ks <= 2 ? launch_stream<4, 2, 2>(p, s) : launch_stream<4, 4, 1>(p, s);
+    }
     return p.M <= 32 ? launch_stream_mt<1>(p, s) : launch_stream_mt<2>(p, s);
 }

@@ -988,6 +988,56 @@ def test_activation_after_residual_and_elu_derivative_from_output():
     close(dx, want, TOL[torch.bfloat16], "dgrad * ELU'(from output)")
 
 
+def test_streaming_kernel_with_128_output_channels_matches_direct_kernel():
+    """conv_stream_kernel's 128-channel form (M <= 128 with K <= 64: four m-tiles, the epilogue in two rounds of 64 channels through
+    the same per-wave stage) -- the wide residual unit's second conv 64 -> 128 k1 with the shortcut as residual and ELU after the
+    sum, plain, with a residual, with a LeakyReLU, and as a data gradient with a derivative source -- forced (GA_IMPL_MFMA_STREAM)
+    against the direct kernel on the same bf16 operands; ragged row counts, M not a multiple of 32."""
+    torch.manual_seed(41)
+    for g, Ln, B in ((ConvGeom("cconv", 64, 128, 1), 1501, 3), (ConvGeom("cconv", 32, 96, 1), 333, 2), (ConvGeom("cconv", 16, 128, 3), 70, 5),
+                     (ConvGeom("cconv", 64, 72, 1), 4099, 2), (ConvGeom("cconv", 64, 128, 1), 15000, 8)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        res = torch.randn(B, Ln, g.cout, device=DEV).bfloat16()
+        w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        wf = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16)
+        p = ops.fwd_params(g, B, Ln)
+        p.x = p.w = p.y = 256
+        assert L.lib().ga_conv_kernel_id(C.byref(p), L.DT_BF16, L.IMPL_AUTO) == L.KERNEL_STREAM
+        variants = (dict(), dict(res=res), dict(res=res, post_act=L.ACT_ELU, act_after_res=True), dict(post_act=L.ACT_LRELU))
+        for kw in variants:
+            outs = {}
+            for name, impl in (("stream", L.IMPL_MFMA_STREAM), ("direct", L.IMPL_DIRECT)):
+                if name == "direct" and kw.get("act_after_res"):
+                    continue
+                ops.set_conv_impl(impl)
+                try:
+                    outs[name] = ops.conv_forward(g, x, wf, bias, **kw).float().cpu()
+                finally:
+                    ops.set_conv_impl(L.IMPL_AUTO)
+            if "direct" in outs:
+                close(outs["stream"], outs["direct"], 1e-2, f"stream M={g.cout} {sorted(kw)} L={Ln}")
+            else:  # ELU(conv + bias + res): from the plain launch's pieces
+                ops.set_conv_impl(L.IMPL_DIRECT)
+                try:
+                    plain = ops.conv_forward(g, x, wf, bias).float().cpu()
+                finally:
+                    ops.set_conv_impl(L.IMPL_AUTO)
+                close(outs["stream"], F.elu(plain + res.float().cpu()), 1.5e-2, f"stream M={g.cout} ELU after the sum L={Ln}")
+        if g.k == 1:  # as a data gradient (of a cout -> cin k1 conv) with ELU' from a derivative source
+            gd = ConvGeom("cconv", g.cout, g.cin, 1)
+            wd = ops.pack_weight(gd, torch.randn(*gd.wdims, device=DEV) / g.cin ** 0.5, gd.dgrad_pack, torch.bfloat16)
+            src = torch.randn(B, Ln, g.cout, device=DEV).bfloat16()
+            outs = {}
+            for name, impl in (("stream", L.IMPL_MFMA_STREAM), ("direct", L.IMPL_DIRECT)):
+                ops.set_conv_impl(impl)
+                try:
+                    outs[name] = ops.conv_dgrad(gd, x, wd, Ln, dact_mode=L.DACT_ELU_FROM_IN, dact_src=src).float().cpu()
+                finally:
+                    ops.set_conv_impl(L.IMPL_AUTO)
+            close(outs["stream"], outs["direct"], 1e-2, f"stream dgrad M={g.cout} L={Ln}")
+
+
 def test_fused_residual_unit_matches_three_node_form():
     """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
     block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
