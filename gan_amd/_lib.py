@@ -75,7 +75,7 @@ class WgradParams(C.Structure):
 
 class ResunitParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "y", "t_act", "w_sc", "b_sc", "w1", "b1", "w3", "b3")] + \
-               [(n, C.c_int) for n in ("B", "L", "C")] + [(n, C.c_void_p) for n in ("w_last", "b_last", "wav")]
+               [(n, C.c_int) for n in ("B", "L", "C")] + [(n, C.c_void_p) for n in ("w_last", "b_last", "wav")] + [("post_elu", C.c_int)]
 
 
 class ResunitBwdParams(C.Structure):

@@ -335,16 +335,20 @@ static int launch_resunit(const ga_resunit_params& p, hipStream_t s) {
     return GA_OK;
 }
 
+static int launch_resunit_wide(const ga_resunit_params& p, hipStream_t s);
+
 extern "C" int ga_resunit_fwd(const ga_resunit_params* hp, int dtype, hipStream_t s) {
     if (!hp) return GA_ERR_ARG;
     const ga_resunit_params& p = *hp;
     if (!p.x || !p.w_sc || !p.b_sc || !p.w1 || !p.b1 || !p.w3 || !p.b3 || p.B < 0 || p.L < 0) return GA_ERR_ARG;
     if (p.wav ? (p.y || p.t_act || !p.w_last) : !p.y) return GA_ERR_ARG;  // the tail form writes the waveform only
-    if (dtype != GA_DTYPE_BF16 || (p.C != 32 && p.C != 64) || p.L < 3) return GA_ERR_UNSUPPORTED;
+    if (dtype != GA_DTYPE_BF16 || (p.C != 32 && p.C != 64 && p.C != 128) || p.L < 3) return GA_ERR_UNSUPPORTED;
     if (p.wav && (p.C != 32 || p.L < 13)) return GA_ERR_UNSUPPORTED;
+    if (p.post_elu && p.C != 128) return GA_ERR_UNSUPPORTED;
     if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.t_act | (uintptr_t)p.w_sc | (uintptr_t)p.w1 | (uintptr_t)p.w3 | (uintptr_t)p.w_last) & 15)
         return GA_ERR_ALIGN;
     if (p.B == 0) return GA_OK;
+    if (p.C == 128) return launch_resunit_wide(p, s);
     if (p.wav) return launch_resunit<32, 4, 2, 8, true>(p, s);
     return p.C == 32 ? launch_resunit<32, 4, 2, 8, false>(p, s) : launch_resunit<64, 2, 2, 8, false>(p, s);
 }
@@ -623,4 +627,201 @@ extern "C" int ga_resunit_bwd(const ga_resunit_bwd_params* hp, int dtype, hipStr
         return GA_ERR_ALIGN;
     if (p.B == 0) return GA_OK;
     return p.C == 32 ? launch_resunit_bwd<32, 2, 6>(p, s) : launch_resunit_bwd<64, 2, 6>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 128-channel unit (15000 steps per item) as one pass.  Its three weight matrices are 96 KB: too many registers for one
+// wave, so here a WORKGROUP of four waves owns a tile of 64 steps and splits the output channels: wave w holds rows 32w..32w+31
+// of W_sc and W3 and one (32 hidden channels x 32 steps) quarter of the hidden product (all 24 K-steps of W1's rows) -- 144
+// weight registers.  The window (66 rows of 256 bytes, one row per 256-byte line, slots XOR-swizzled by the row) is loaded
+// cooperatively one tile ahead (five direct-to-LDS loads per wave) and shared; four workgroup barriers per tile order the
+// phases: shortcut on the raw window | ELU in place | hidden quarter -> bf16, ELU -> shared stage | second conv, epilogue.
+// Two workgroups per CU overlap one another's phases.
+struct RuWideCfg {
+    static constexpr int C = 128, H = 64, NT = 2, NR = 64, RD = 2;
+    static constexpr int WROWS = NR + 2;
+    static constexpr int WCH = WROWS * 16;                 // 16-byte chunks of a window
+    static constexpr int NLW = 5;                          // loads per wave and tile (4 waves x 64 lanes x 5 >= WCH; the rest hits a pad)
+    static constexpr int SLOT = NLW * 4096;
+    static constexpr int HROW = H * 2 + 16;                // shared hidden stage: 64 rows
+    static constexpr int HSTAGE = NR * HROW;
+    static constexpr int YROW = 72, YSTAGE = 2304;         // per-wave output stage (32 rows x 32 channels)
+    static constexpr int BIAS_OFF = RD * SLOT + HSTAGE + 4 * YSTAGE;
+    static constexpr int LDS = BIAS_OFF + 1024;
+    static_assert(WCH <= NLW * 256, "loads");
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+// workgroup barrier that the compiler cannot move LDS accesses across (the s_barrier builtin is "no memory" to it), with this
+// wave's LDS operations complete first
+#define RU_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool POST_ELU>
+__global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params p, int tiles_per_item, int total) {
+    typedef RuWideCfg G;
+    constexpr int C = G::C, H = G::H, NT = G::NT, NR = G::NR, RD = G::RD, SLOT = G::SLOT, HROW = G::HROW, YROW = G::YROW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+    char* const hstage = smem + RD * SLOT;
+    char* const ystage = hstage + G::HSTAGE + wid * G::YSTAGE;
+    float* const bsum = (float*)(smem + G::BIAS_OFF);
+    float* const b1s = bsum + C;
+    for (int i = tid; i < C + H; i += 256) bsum[i] = i < C ? p.b_sc[i] + p.b3[i] : p.b1[i - C];
+    __syncthreads();
+
+    const bf16_t* __restrict__ wsc = (const bf16_t*)p.w_sc;
+    const bf16_t* __restrict__ w1 = (const bf16_t*)p.w1;
+    const bf16_t* __restrict__ w3 = (const bf16_t*)p.w3;
+    const int hm = wid & 1, hn = wid >> 1;  // this wave's quarter of the hidden product: hidden channels 32hm.., steps 32hn..
+    bf16x8 asc[8], a3[4], a1[24];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asc[ks] = *(gfrag_ptr_t)(wsc + (size_t)(wid * 32 + r) * C + ks * 16 + h * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a3[ks] = *(gfrag_ptr_t)(w3 + (size_t)(wid * 32 + r) * H + ks * 16 + h * 8);
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) a1[ks] = *(gfrag_ptr_t)(w1 + (size_t)(hm * 32 + r) * (3 * C) + ks * 16 + h * 8);
+
+    // cooperative fill: load i of wave w puts chunk P = i*256 + w*64 + lane at LDS offset 16 P: row P >> 4, logical chunk (P & 15) ^ (row & 15)
+    int wsrc[G::NLW];  // byte offset in the item's rows, or -1: pad
+#pragma unroll
+    for (int i = 0; i < G::NLW; ++i) {
+        const int P = i * 256 + wid * 64 + lane, row = P >> 4, ch = (P & 15) ^ (row & 15);
+        wsrc[i] = P < G::WCH ? row * 256 + ch * 16 : -1;
+    }
+    bf16_t* __restrict__ y = (bf16_t*)p.y;
+    bf16_t* __restrict__ tact = (bf16_t*)p.t_act;
+    const int L = p.L;
+
+    auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+        const bool valid = t < total;
+        const int tt = valid ? t : 0;
+        const int b = tt / tiles_per_item, R0 = (tt - b * tiles_per_item) * NR - 2;
+        const uintptr_t xb = (uintptr_t)p.x + (size_t)b * L * 256;
+        char* const dst = smem + slot * SLOT + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < G::NLW; ++i) {
+            int R = R0 + (wsrc[i] >> 8);
+            if (R < 0) R = -R;  // reflect-left padding of the causal conv
+            const bool ok = valid && wsrc[i] >= 0 && R < L;
+            sw_glds16(sw_sel(ok, xb + (size_t)(ok ? R : 0) * 256 + (wsrc[i] & 255), zero), dst + i * 4096);
+        }
+    };
+    // B fragment of (tap, k-step kk) for row r (+ 32 rows: + 8192 bytes): chunk 2 kk + h of window row r + tap
+    auto frag = [&](const char* Wl, int nt, int tap, int kk) __attribute__((always_inline)) -> bf16x8 {
+        const int row = r + tap;
+        return *(const bf16x8*)(Wl + nt * 8192 + row * 256 + (((2 * kk + h) ^ (row & 15)) << 4));
+    };
+
+    int t = blockIdx.x;
+#pragma unroll
+    for (int d = 0; d < RD - 1; ++d) issue(t + d * gridDim.x, d);
+    for (int it = 0; t < total; t += gridDim.x, ++it) {
+        asm volatile("" ::: "memory");
+        issue(t + (RD - 1) * gridDim.x, (it + RD - 1) % RD);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * G::NLW) : "memory");
+        RU_WG_BARRIER();  // every wave's part of the window has landed
+        char* const Wl = smem + (it % RD) * SLOT;
+        const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NR;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[kk], frag(Wl, nt, 2, kk), acc[nt], 0, 0, 0);
+        }
+        RU_WG_BARRIER();  // the raw window has been read by everyone
+#pragma unroll
+        for (int i = 0; i < G::NLW; ++i)
+            if (wsrc[i] >= 0) {
+                char* const q = Wl + (i * 256 + wid * 64 + lane) * 16;
+                sw_lds_write16(q, sw_elu8(*(const u32x4*)q));
+            }
+        RU_WG_BARRIER();  // ELU(window) complete
+        {
+            f32x16 ta;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ta[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], frag(Wl, hn, ks >> 3, ks & 7), ta, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const ru_f32x4 bb = *(const ru_f32x4*)(b1s + hm * 32 + 8 * q + 4 * h);
+                u32x2 o;
+                o.x = sw_elu2(sw_pack_bf16(ta[4 * q] + bb[0], ta[4 * q + 1] + bb[1]));
+                o.y = sw_elu2(sw_pack_bf16(ta[4 * q + 2] + bb[2], ta[4 * q + 3] + bb[3]));
+                sw_lds_write8(hstage + (hn * 32 + r) * HROW + (hm * 32 + 8 * q + 4 * h) * 2, o);
+            }
+        }
+        RU_WG_BARRIER();  // hidden stage complete (and nobody reads the window any more)
+        if (tact) {  // 64 rows x 128 bytes of ELU(hidden): 512 pieces over 256 lanes
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int piece = ps * 256 + tid, row = piece >> 3, c0 = (piece & 7) * 8;
+                const int tl = tl0 + row;
+                const u32x4 v = *(const u32x4*)(hstage + row * HROW + c0 * 2);
+                if (tl < L) *(u32x4*)(tact + ((size_t)b * L + tl) * H + c0) = v;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 tb = *(const bf16x8*)(hstage + (nt * 32 + r) * HROW + (ks * 16 + h * 8) * 2);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks], tb, acc[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const ru_f32x4 bb = *(const ru_f32x4*)(bsum + wid * 32 + 8 * q + 4 * h);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[nt][4 * q + i] + bb[i];
+                    if (POST_ELU) v[i] = elu_bf16_grade(v[i]);
+                }
+                u32x2 o;
+                o.x = sw_pack_bf16(v[0], v[1]);
+                o.y = sw_pack_bf16(v[2], v[3]);
+                sw_lds_write8(ystage + r * YROW + (8 * q + 4 * h) * 2, o);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = ps * 16 + (lane >> 2), m0 = (lane & 3) * 8;
+                const int tl = tl0 + nt * 32 + row;
+                const u32x2 lo = *(const u32x2*)(ystage + row * YROW + m0 * 2), hi = *(const u32x2*)(ystage + row * YROW + m0 * 2 + 8);
+                u32x4 ov;
+                ov.x = lo.x; ov.y = lo.y; ov.z = hi.x; ov.w = hi.y;
+                if (tl < L) *(u32x4*)(y + ((size_t)b * L + tl) * C + wid * 32 + m0) = ov;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int launch_resunit_wide(const ga_resunit_params& p, hipStream_t s) {
+    typedef RuWideCfg G;
+    const int tpi = (p.L + G::NR - 1) / G::NR;
+    const long total = (long)p.B * tpi;
+    if (total <= 0) return GA_OK;
+    if (total > (1L << 30)) return GA_ERR_UNSUPPORTED;
+    static bool attr_set[16][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return GA_ERR_LAUNCH;
+    const int v = p.post_elu ? 1 : 0;
+    if (!attr_set[dev][v]) {
+        const void* k = v ? (const void*)resunit_wide_fwd_kernel<true> : (const void*)resunit_wide_fwd_kernel<false>;
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return GA_ERR_LAUNCH;
+        attr_set[dev][v] = true;
+    }
+    const int grid = (int)(total < 512 ? total : 512);  // two workgroups per CU
+    if (v) resunit_wide_fwd_kernel<true><<<grid, 256, G::LDS, s>>>(p, tpi, (int)total);
+    else resunit_wide_fwd_kernel<false><<<grid, 256, G::LDS, s>>>(p, tpi, (int)total);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
 }

@@ -888,18 +888,21 @@ def _frozen_forward(geom: ConvGeom, x: Tensor, wp_f: Tensor, bias, pre_act: int,
 
 
 FUSE_RESUNIT = os.environ.get("GA_FUSE_RESUNIT", "1") != "0"  # False: a thin residual unit's forward as three ga_conv launches (A/B checks)
+FUSE_RESUNIT_WIDE = os.environ.get("GA_FUSE_RESUNIT_WIDE", "1") != "0"  # False: the 128-channel unit stays three launches
 
 
 def resunit_fusable(x: Tensor, g_sc: ConvGeom, g1: ConvGeom, g3: ConvGeom) -> bool:
-    """True when ga_resunit_fwd takes this residual unit: bf16, C in {32, 64} -> C/2 -> C, causal k3 / k1 / k1 shortcut."""
+    """True when ga_resunit_fwd takes this residual unit: bf16, C in {32, 64, 128} -> C/2 -> C, causal k3 / k1 / k1 shortcut."""
     c = g_sc.cin
-    return (FUSE_RESUNIT and x.dtype == torch.bfloat16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) and c in (32, 64) and x.shape[1] >= 3
+    return (FUSE_RESUNIT and x.dtype == torch.bfloat16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA) and x.shape[1] >= 3
+            and (c in (32, 64) or (c == 128 and FUSE_RESUNIT_WIDE))
             and all(g.kind == "cconv" and g.dilation == 1 for g in (g_sc, g1, g3))
             and (g_sc.cin, g_sc.cout, g_sc.k) == (c, c, 1) and (g1.cin, g1.cout, g1.k) == (c, c // 2, 3)
             and (g3.cin, g3.cout, g3.k) == (c // 2, c, 1))
 
 
-def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: Tensor, b3_f: Tensor, b3_b: Tensor, want_t: bool, last=None):
+def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: Tensor, b3_f: Tensor, b3_b: Tensor, want_t: bool, last=None,
+                    post_elu: bool = False):
     """(y, ELU(hidden) or None) of one residual unit in one launch (ga_resunit_fwd).
     last = (forward pack [1][7][32], bias) of the decoder's closing conv: the tail form -- returns (wav [B, L, 1] fp32, None)
     and neither y nor the hidden tensor exists (callers that need no gradient)."""
@@ -921,7 +924,7 @@ def resunit_forward(x: Tensor, sc_f: Tensor, sc_b: Tensor, b1_f: Tensor, b1_b: T
     else:
         y = torch.empty_like(x)
         t = torch.empty((B, lin, c // 2), device=x.device, dtype=x.dtype) if want_t else None
-        _fill(p, y=y.data_ptr(), t_act=L.ptr(t))
+        _fill(p, y=y.data_ptr(), t_act=L.ptr(t), post_elu=1 if post_elu else 0)
     _fill(p, x=x.data_ptr(), w_sc=sc_f.data_ptr(), b_sc=sc_b.data_ptr(), w1=b1_f.data_ptr(),
           b1=b1_b.data_ptr(), w3=b3_f.data_ptr(), b3=b3_b.data_ptr(), B=B, L=lin, C=c)
     if PROFILE is None:
@@ -980,10 +983,10 @@ class ResBlockFrozen(torch.autograd.Function):
                 elu_mid: bool = False, elu_out: bool = False, x_elu=None):
         """x_elu: ELU(x), already written by x's producer (ConvFrozen also_elu): the first conv reads it instead of a pass over x."""
         x = x.contiguous()
-        if not elu_out and resunit_fusable(x, g_sc, g1, g3):
-            # the thin units (32 / 64 channels): one pass over x instead of three launches; the hidden tensor is kept, as ELU(t),
-            # only when a gradient will come back
-            y, t = resunit_forward(x, sc_f, sc_b, b1_f, b1_b, b3_f, b3_b, want_t=ctx.needs_input_grad[0])
+        if (not elu_out or g_sc.cin == 128) and resunit_fusable(x, g_sc, g1, g3):
+            # the 32 / 64 / 128-channel units: one pass over x instead of three launches; the hidden tensor is kept, as ELU(t),
+            # only when a gradient will come back (elu_out: the 128-channel kernel writes ELU(y), as GA_RES_ADD_THEN_ACT does)
+            y, t = resunit_forward(x, sc_f, sc_b, b1_f, b1_b, b3_f, b3_b, want_t=ctx.needs_input_grad[0], post_elu=elu_out)
             ctx.geoms, ctx.elu_mid, ctx.one_launch = (g_sc, g1, g3), True, True
             ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
             return y
@@ -1006,7 +1009,7 @@ class ResBlockFrozen(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous().to(x.dtype)
-            if ctx.one_launch and FUSE_RESUNIT_BWD:
+            if ctx.one_launch and FUSE_RESUNIT_BWD and x.shape[2] in (32, 64):
                 return (resunit_backward(gy, t, x, sc_d, b1_d, b3_d),) + (None,) * 15
             gt = conv_dgrad(g3, gy, b3_d, t.shape[1], dact_mode=L.DACT_ELU_FROM_OUT if ctx.elu_mid else L.DACT_ELU_FROM_IN, dact_src=t)
             gb = conv_dgrad(g1, gt, b1_d, x.shape[1], dact_mode=L.DACT_ELU_FROM_IN, dact_src=x)

@@ -178,7 +178,8 @@ int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
  *   x, y [B][L][C] channels-last; weights in ga_conv's packed forward layout (GA_PACK_CONV_FWD): w_sc [C][C], w1 [C/2][3][C],
  *   w3 [C][C/2]; biases fp32.  t_act (optional, [B][L][C/2]) receives ELU(conv_k3(ELU(x)) + b1), which the data gradient of
  *   conv_k1 needs (GA_DACT_ELU_FROM_OUT).  The shortcut stays in fp32 until the single rounding of y (the three-launch form
- *   rounds it to bf16 first).  C in {32, 64}, L >= 3, 16-byte aligned pointers; anything else returns GA_ERR_UNSUPPORTED. */
+ *   rounds it to bf16 first).  C in {32, 64, 128}, L >= 3, 16-byte aligned pointers; anything else returns GA_ERR_UNSUPPORTED.
+ *   (C = 128: the weights do not fit one wave's registers; a workgroup of four waves shares the window and splits the channels.) */
 typedef struct ga_resunit_params {
     const void* x;
     void* y;
@@ -198,6 +199,8 @@ typedef struct ga_resunit_params {
     const void* w_last;
     const float* b_last;
     float* wav;
+    int post_elu; /* C == 128 only: y receives ELU(unit output) (the transposed conv behind the unit reads it through ELU only:
+                     what GA_RES_ADD_THEN_ACT does in the three-launch form) */
 } ga_resunit_params;
 int ga_resunit_fwd(const ga_resunit_params* h_params, int dtype, ga_stream_t stream);
 /* The same unit's input gradient as one pass (autograd of the call above, reached from loss_g.backward(),

@@ -52,6 +52,6 @@ if "bwd" in sys.argv:
         for B in (64, 12):
             run_bwd(c, lin, B)
     sys.exit(0)
-for c, lin in ((32, 120000), (64, 60000)):
+for c, lin in ((128, 15000), (32, 120000), (64, 60000)):
     for B, wg in ((192, False), (64, True), (36, False), (12, True)):
         run(c, lin, B, wg)

@@ -1071,7 +1071,8 @@ def test_fused_residual_unit_matches_three_node_form():
 
 
 @pytest.mark.parametrize("c,lin,B", [(32, 3, 2), (32, 131, 3), (32, 4173, 2), (64, 5, 1), (64, 64, 2), (64, 2013, 3),
-                                     (32, 120000, 2), (64, 60000, 3)])
+                                     (32, 120000, 2), (64, 60000, 3), (128, 3, 2), (128, 64, 1), (128, 65, 3), (128, 1501, 2),
+                                     (128, 15000, 9)])
 def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c, lin, B):
     """ga_resunit_fwd (the thin residual units of the decoder, HF modeling_encodec.py:320-343, as one pass over x) against the
     three ga_conv launches it replaces and against torch fp32 on the same bf16-rounded weights: forward to bf16 accuracy
@@ -1109,10 +1110,25 @@ def test_one_launch_residual_unit_matches_three_launch_form_and_fp32_reference(c
     # ELU'(x), shortcut) against the three data-gradient launches + fix-up launch on the same saved tensors
     y1b, gx1b, _ = run(True, True)
     assert torch.equal(y1b, y1)
+    if c == 128:  # the unit that hands ELU(output) to the transposed conv behind it: post_elu against GA_RES_ADD_THEN_ACT
+        outs = []
+        for fuse in (True, False):
+            old = ops.FUSE_RESUNIT
+            ops.FUSE_RESUNIT = fuse
+            try:
+                with torch.no_grad():
+                    outs.append(ops.ResBlockFrozen.apply(x.to(DEV), *packs["sc"], bd["sc"], g_sc, *packs["b1"], bd["b1"], g1, *packs["b3"], bd["b3"], g3,
+                                                         True, True).float().cpu())
+            finally:
+                ops.FUSE_RESUNIT = old
+        close(outs[0], outs[1], 1e-2, "one-launch 128-channel unit with ELU on the output")
+        close(outs[0], F.elu(y1), 1e-2, "ELU(output) vs ELU of the plain output")
     close(gx1b, gx1, 1e-2, "one-launch input gradient vs three launches")
     assert h1.shape == (B, lin, c // 2)
     href = F.elu(h3).bfloat16().float()  # (exp2-based ELU in the kernel, expm1 here: one bf16 step apart at most)
-    assert ((h1 - href).abs() <= 2.0 ** -7 * href.abs().clamp_min(1e-3)).all()
+    # (C = 128: the three-launch form's first conv runs on the gathered-GEMM kernel, whose fp32 sums go in another K order, so a
+    # few hidden values in ten million round to the neighbouring bf16 before the ELU: two steps there)
+    assert ((h1 - href).abs() <= 2.0 ** (-6 if c == 128 else -7) * href.abs().clamp_min(1e-3)).all()
     close(y1, y3, 1e-2, "one-launch unit vs three launches, y")
     close(gx1, gx3, 1e-2, "one-launch unit vs three launches, dx")
     if lin <= 5000:
