@@ -23,8 +23,9 @@ KERNEL_STREAM = 10
 KERNEL_GEMM_PP = 11
 KERNEL_CONV_WIN = 12
 KERNEL_STREAM_WIN = 13
+KERNEL_COOP = 16
 KERNEL_RESUNIT, KERNEL_RESUNIT_BWD = 14, 15  # ga_resunit_fwd / _bwd (not ga_conv kernels: the benchmark's per-kernel accounting only)
-GEMM_KERNELS = (7, 8, 9, 10, 11, 12, 13)  # MFMA kernels whose operands never pass through a conv window in LDS
+GEMM_KERNELS = (7, 8, 9, 10, 11, 12, 13, 16)  # MFMA kernels whose operands never pass through a conv window in LDS
 PACK_CONV_FWD, PACK_CONV_DGRAD_S1, PACK_CONV_DGRAD_STRIDED, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3, 4
 RED_ABSDIFF, RED_RELU1M, RED_RELU1P, RED_SUM, RED_SQ = 0, 1, 2, 3, 4
 

@@ -12,6 +12,7 @@ int ga_conv_gemm_suggest_ksplit(const ConvParams& p);
 int ga_conv_splitk_static_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_win_supported(const ConvParams& p);
 int ga_conv_win_wanted(const ConvParams& p);
+int ga_conv_coop_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_pp_supported(const ConvParams& p);
 int ga_conv_pp_wanted(const ConvParams& p);
@@ -109,6 +110,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
         return GA_KERNEL_STREAM;  // (as ga_conv: the streaming kernels are asked first)
     if (p.res_mode != GA_RES_ADD || p.y2) {  // ga_conv: gathered-GEMM kernel or nothing
         if (!(can_gemm && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA))) return -1;
+        if (ga_conv_coop_wanted(p)) return GA_KERNEL_COOP;
         if (ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
         if (ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
         return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;
@@ -116,6 +118,7 @@ int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (dtype == GA_DTYPE_BF16 && impl == GA_IMPL_AUTO && p.M == 1 && ga_conv_swin_wanted(p)) return GA_KERNEL_STREAM_WIN;
     if (dtype == GA_DTYPE_BF16 && (impl == GA_IMPL_AUTO || impl == GA_IMPL_MFMA) && ga_conv_stream_supported(p))
         return ga_conv_swin_wanted(p) ? GA_KERNEL_STREAM_WIN : GA_KERNEL_STREAM;
+    if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_coop_wanted(p)) return GA_KERNEL_COOP;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_win_wanted(p)) return GA_KERNEL_CONV_WIN;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big)) && ga_conv_pp_wanted(p)) return GA_KERNEL_GEMM_PP;
     if (can_gemm && (impl == GA_IMPL_MFMA || (impl == GA_IMPL_AUTO && big))) return p.M <= 32 ? GA_KERNEL_GEMM_32x256 : p.M <= 64 ? GA_KERNEL_GEMM_64x256 : GA_KERNEL_GEMM_128x128;

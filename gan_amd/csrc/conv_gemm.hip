@@ -626,12 +626,15 @@ int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_win_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_coop_wanted(const ConvParams& p);
+int ga_conv_coop_impl(const ConvParams& p, hipStream_t s);
 
 int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (!ga_conv_gemm_supported(p) || !p.x || !p.w || !p.y) return GA_ERR_ARG;
     if (p.res_mode == GA_RES_ADD_THEN_ACT && (!p.res || p.ksplit > 1 || p.dact_mode)) return GA_ERR_ARG;
     if (p.y2 && (p.ksplit > 1 || p.out_f32 || ((uintptr_t)p.y2 & 15))) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
+    if (ga_conv_coop_wanted(p)) return ga_conv_coop_impl(p, s);  // many rows, K of a few hundred, 256 channels: weights in registers (conv_coop.hip)
     if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
     if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
     // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K

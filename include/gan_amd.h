@@ -167,6 +167,8 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_STREAM_WIN 13  /* conv_swin_kernel: M <= 64, 2-4 taps, weights in registers, per-wave ring of input windows in LDS */
 #define GA_KERNEL_RESUNIT 14     /* resunit_fwd_kernel (ga_resunit_fwd below; never returned by ga_conv_kernel_id) */
 #define GA_KERNEL_RESUNIT_BWD 15 /* resunit_bwd_kernel (ga_resunit_bwd) */
+#define GA_KERNEL_COOP 16        /* conv_coop_kernel: 256 output channels, K = 2 x 128, many rows: weights in the registers of an
+                                    eight-wave workgroup, shared input window (the decoder's transposed conv 128 -> 4 x 64) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
 
 /* One SEANet residual unit of the frozen decoder, forward, as ONE pass over its input (bf16):

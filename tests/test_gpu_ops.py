@@ -1038,6 +1038,36 @@ def test_streaming_kernel_with_128_output_channels_matches_direct_kernel():
             close(outs["stream"], outs["direct"], 1e-2, f"stream dgrad M={g.cout} L={Ln}")
 
 
+def test_cooperative_weights_in_registers_kernel_matches_direct_kernel():
+    """conv_coop_kernel (the decoder's transposed conv 128 -> 64 k8 s4 folded to 256 channels x 2 taps: weights in the registers of
+    an eight-wave workgroup, shared input window, zero padding at both ends) against the direct kernel on the same bf16 operands,
+    and against torch; AUTO takes it for long launches only; lengths: ragged last tile, one tile, several tiles per workgroup."""
+    torch.manual_seed(43)
+    g = ConvGeom("convt", 128, 64, 8, 4)
+    w = torch.randn(*g.wdims, device=DEV) / (128 * 2) ** 0.5
+    bias = torch.randn(64, device=DEV)
+    wf = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16)
+    for B, Ln in ((3, 50000), (1, 140000), (40, 15000), (2, 40)):
+        x = torch.randn(B, Ln, 128, device=DEV).bfloat16()
+        p = ops.fwd_params(g, B, Ln)
+        p.x = p.w = p.y = 256
+        q, _ = ops._fold_phases(p, x, None)
+        kid = L.lib().ga_conv_kernel_id(C.byref(q), L.DT_BF16, L.IMPL_AUTO)
+        assert kid == (L.KERNEL_COOP if B * Ln >= 2 ** 15 else 8), (B, Ln, kid)
+        y = ops.conv_forward(g, x, wf, bias).float().cpu()
+        assert y.shape == (B, 4 * Ln, 64)
+        if Ln <= 50000:
+            ops.set_conv_impl(L.IMPL_DIRECT)
+            try:
+                yd = ops.conv_forward(g, x, wf, bias).float().cpu()
+            finally:
+                ops.set_conv_impl(L.IMPL_AUTO)
+            close(y, yd, 1e-2, f"coop vs direct B={B} L={Ln}")
+        if B * Ln <= 200000:
+            ref = _ref_conv(g, x.float().cpu().permute(0, 2, 1), w.bfloat16().float().cpu(), bias.cpu(), 0, 0)
+            close(y, ref.permute(0, 2, 1), TOL[torch.bfloat16], f"coop vs torch B={B} L={Ln}")
+
+
 def test_fused_residual_unit_matches_three_node_form():
     """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
     block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
