@@ -27,7 +27,7 @@ sys.path.insert(0, str(REPO))
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_NAMES = {0: "conv_direct_kernel", 1: "conv_fewout_kernel", 2: "conv_cin1_kernel",
                 3: "conv_mfma_kernel<1,4,32>", 4: "conv_mfma_kernel<2,2,64>", 5: "conv_fewout_rows_kernel",
-                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>", 10: "conv_stream_kernel", 11: "conv_pp_kernel", 12: "conv_win_kernel", 13: "conv_swin_kernel", 14: "resunit_fwd_kernel", 15: "resunit_bwd_kernel", 16: "conv_coop_kernel"}
+                6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>", 10: "conv_stream_kernel", 11: "conv_pp_kernel", 12: "conv_win_kernel", 13: "conv_swin_kernel", 14: "resunit_fwd_kernel", 15: "resunit_bwd_kernel", 16: "conv_coop_kernel", 17: "conv_dual_k1_kernel"}
 
 
 def make_models(precision: str, device, seed: int):

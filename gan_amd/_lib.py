@@ -23,7 +23,7 @@ KERNEL_STREAM = 10
 KERNEL_GEMM_PP = 11
 KERNEL_CONV_WIN = 12
 KERNEL_STREAM_WIN = 13
-KERNEL_COOP = 16
+KERNEL_COOP, KERNEL_DUAL_K1 = 16, 17
 KERNEL_RESUNIT, KERNEL_RESUNIT_BWD = 14, 15  # ga_resunit_fwd / _bwd (not ga_conv kernels: the benchmark's per-kernel accounting only)
 GEMM_KERNELS = (7, 8, 9, 10, 11, 12, 13, 16)  # MFMA kernels whose operands never pass through a conv window in LDS
 PACK_CONV_FWD, PACK_CONV_DGRAD_S1, PACK_CONV_DGRAD_STRIDED, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3, 4
@@ -83,6 +83,11 @@ class ResunitBwdParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("gy", "t_act", "x", "gx", "w_sc_d", "w1_d", "w3_d")] + [(n, C.c_int) for n in ("B", "L", "C")]
 
 
+class DualK1Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xa", "wa", "ba", "xb", "wb", "bb", "y")] + [("rows", C.c_long)] + \
+               [(n, C.c_int) for n in ("Ca", "Cb", "M", "post_elu")]
+
+
 class LstmParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "bias2", "xg1", "x_in", "y", "h1", "h2", "c1", "c2", "gates1", "gates2",
                                           "cs1", "cs2")] + [(n, C.c_int) for n in ("B", "T", "H", "act_dtype", "w_dtype", "B_save")] + \
@@ -103,6 +108,7 @@ _SIGNATURES = {
     "ga_conv_splitk_static": [C.POINTER(ConvParams), _I, _P],
     "ga_resunit_fwd": [C.POINTER(ResunitParams), _I, _P],
     "ga_resunit_bwd": [C.POINTER(ResunitBwdParams), _I, _P],
+    "ga_conv_dual_k1": [C.POINTER(DualK1Params), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
     "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],

@@ -166,3 +166,156 @@ int ga_conv_coop_impl(const ConvParams& p, hipStream_t s) {
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The closing sum of the 256-channel residual unit in one pass: y = [ELU]( W_sc x + W3 t + b_sc + b3 ), x [rows][256], t [rows][128],
+// 256 output channels (HF modeling_encodec.py:333-343: shortcut(x) + block's last conv k1).  Both convs are k1, so the problem is
+// row-wise -- one GEMM over the concatenated K = 256 + 128 -- and has no item boundaries.  As two gathered-GEMM launches the
+// shortcut was written and read back and each launch was two / four K-steps per tile.  Same scheme as conv_coop_kernel: the 192 KB
+// of [W_sc | W3] live in the registers of an eight-wave workgroup (96 per wave), the 64 rows of x and t of a tile go global -> LDS
+// once per workgroup one tile ahead (exactly six loads per wave), one barrier per tile.
+struct DualCfg {
+    static constexpr int CA = 256, CB = 128, M = 256, WAVES = 8, NR = 64, NT = 2;
+    static constexpr int XA_BYTES = NR * CA * 2, XB_BYTES = NR * CB * 2;   // 32 KB + 16 KB
+    static constexpr int SLOT = XA_BYTES + XB_BYTES;
+    static constexpr int NLA = XA_BYTES / (WAVES * 1024), NLB = XB_BYTES / (WAVES * 1024);  // 4 + 2 loads per wave
+    static constexpr int KSA = CA / 16, KSB = CB / 16;
+    static constexpr int YROW = 72, YSTAGE = 2304;
+    static constexpr int RD = 2;
+    static constexpr int LDS = RD * SLOT + WAVES * YSTAGE;
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+template <bool POST_ELU>
+__global__ __launch_bounds__(512) void conv_dual_k1_kernel(ga_dual_k1_params p, int total) {
+    typedef DualCfg G;
+    constexpr int NR = G::NR, NT = G::NT, SLOT = G::SLOT, YROW = G::YROW, RD = G::RD, M = G::M, WAVES = G::WAVES;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uintptr_t zero = (uintptr_t)ga_zero_page;
+    char* const ystage = smem + RD * SLOT + wid * G::YSTAGE;
+    const bf16_t* __restrict__ wa = (const bf16_t*)p.wa;
+    const bf16_t* __restrict__ wb = (const bf16_t*)p.wb;
+    bf16x8 aa[G::KSA], ab[G::KSB];
+#pragma unroll
+    for (int ks = 0; ks < G::KSA; ++ks) aa[ks] = *(gfrag_ptr_t)(wa + (size_t)(wid * 32 + r) * G::CA + ks * 16 + h * 8);
+#pragma unroll
+    for (int ks = 0; ks < G::KSB; ++ks) ab[ks] = *(gfrag_ptr_t)(wb + (size_t)(wid * 32 + r) * G::CB + ks * 16 + h * 8);
+    float bq[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = wid * 32 + 8 * q + 4 * h + i;
+            bq[q][i] = (p.ba ? p.ba[m] : 0.f) + (p.bb ? p.bb[m] : 0.f);
+        }
+    // fill: load i of wave w covers LDS bytes [(i*WAVES + w)*1024, +1024) of a region = lines 4(i*WAVES + w) .. +3; lane's slot holds
+    // logical slot (P & 15) ^ (line & 15) of line P >> 4.  x rows are two lines (512 bytes), t rows one.
+    int srcA[G::NLA], srcB[G::NLB];  // byte offset inside the tile's rows of the source
+#pragma unroll
+    for (int i = 0; i < G::NLA; ++i) {
+        const int P = (i * WAVES + wid) * 64 + lane, line = P >> 4, sl = (P & 15) ^ (line & 15);
+        srcA[i] = line * 256 + sl * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < G::NLB; ++i) {
+        const int P = (i * WAVES + wid) * 64 + lane, line = P >> 4, sl = (P & 15) ^ (line & 15);
+        srcB[i] = line * 256 + sl * 16;
+    }
+    const long rows = p.rows;
+    bf16_t* __restrict__ y = (bf16_t*)p.y;
+
+    auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+        const long row0 = (long)t * NR;
+        const long left = t < total ? rows - row0 : 0;  // rows of this tile that exist
+        const uintptr_t xa = (uintptr_t)p.xa + (size_t)(t < total ? row0 : 0) * (G::CA * 2);
+        const uintptr_t xb = (uintptr_t)p.xb + (size_t)(t < total ? row0 : 0) * (G::CB * 2);
+        char* const dst = smem + slot * SLOT + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < G::NLA; ++i)
+            sw_glds16(sw_sel((srcA[i] >> 9) < left, xa + srcA[i], zero), dst + i * WAVES * 1024);
+#pragma unroll
+        for (int i = 0; i < G::NLB; ++i)
+            sw_glds16(sw_sel((srcB[i] >> 8) < left, xb + srcB[i], zero), dst + G::XA_BYTES + i * WAVES * 1024);
+    };
+
+    int t = blockIdx.x;
+    issue(t, 0);
+    for (int it = 0; t < total; t += gridDim.x, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CC_WG_BARRIER();
+        issue(t + gridDim.x, (it + 1) % RD);
+        const char* const Wa = smem + (it % RD) * SLOT;
+        const char* const Wb = Wa + G::XA_BYTES;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int row = nt * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < G::KSA; ++ks) {  // chunk 2 ks + h of x row `row`: line 2 row + (chunk >> 4)
+                const int c = 2 * ks, line = 2 * row + (c >> 4);
+                const bf16x8 xb = *(const bf16x8*)(Wa + line * 256 + ((((c & 15) + h) ^ (line & 15)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[ks], xb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < G::KSB; ++ks) {
+                const bf16x8 xb = *(const bf16x8*)(Wb + row * 256 + (((2 * ks + h) ^ (row & 15)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[ks], xb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[4 * q + i] + bq[q][i];
+                    if (POST_ELU) v[i] = elu_bf16_grade(v[i]);
+                }
+                u32x2 o;
+                o.x = sw_pack_bf16(v[0], v[1]);
+                o.y = sw_pack_bf16(v[2], v[3]);
+                sw_lds_write8(ystage + r * YROW + (8 * q + 4 * h) * 2, o);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int rr = ps * 16 + (lane >> 2), m0 = (lane & 3) * 8;
+                const long grow = (long)t * NR + nt * 32 + rr;
+                const u32x2 lo = *(const u32x2*)(ystage + rr * YROW + m0 * 2), hi = *(const u32x2*)(ystage + rr * YROW + m0 * 2 + 8);
+                u32x4 ov;
+                ov.x = lo.x; ov.y = lo.y; ov.z = hi.x; ov.w = hi.y;
+                if (grow < rows) *(u32x4*)(y + (size_t)grow * M + wid * 32 + m0) = ov;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+extern "C" int ga_conv_dual_k1(const ga_dual_k1_params* hp, int dtype, hipStream_t s) {
+    if (!hp) return GA_ERR_ARG;
+    const ga_dual_k1_params& p = *hp;
+    if (!p.xa || !p.wa || !p.xb || !p.wb || !p.y || p.rows < 0) return GA_ERR_ARG;
+    if (dtype != GA_DTYPE_BF16 || p.Ca != 256 || p.Cb != 128 || p.M != 256) return GA_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.xa | (uintptr_t)p.wa | (uintptr_t)p.xb | (uintptr_t)p.wb | (uintptr_t)p.y) & 15) return GA_ERR_ALIGN;
+    if (p.rows == 0) return GA_OK;
+    const long total = (p.rows + DualCfg::NR - 1) / DualCfg::NR;
+    if (total > (1L << 30)) return GA_ERR_UNSUPPORTED;
+    static bool attr_set[16][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return GA_ERR_LAUNCH;
+    const int v = p.post_elu ? 1 : 0;
+    if (!attr_set[dev][v]) {
+        const void* k = v ? (const void*)conv_dual_k1_kernel<true> : (const void*)conv_dual_k1_kernel<false>;
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DualCfg::LDS) != hipSuccess) return GA_ERR_LAUNCH;
+        attr_set[dev][v] = true;
+    }
+    const int grid = (int)(total < 256 ? total : 256);  // one workgroup per CU (its LDS: 114 KB)
+    if (v) conv_dual_k1_kernel<true><<<grid, 512, DualCfg::LDS, s>>>(p, (int)total);
+    else conv_dual_k1_kernel<false><<<grid, 512, DualCfg::LDS, s>>>(p, (int)total);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}

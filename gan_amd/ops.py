@@ -966,6 +966,38 @@ def resunit_backward(gy: Tensor, t_act: Tensor, x: Tensor, sc_d: Tensor, b1_d: T
     return gx
 
 
+FUSE_DUAL = os.environ.get("GA_FUSE_DUAL", "1") != "0"  # False: the 256-channel unit's shortcut and last conv stay two ga_conv launches
+
+
+def dual_k1_ok(x: Tensor, g_sc: ConvGeom, g3: ConvGeom) -> bool:
+    """True when ga_conv_dual_k1 takes the unit's closing sum: bf16, shortcut 256 -> 256 k1 and last conv 128 -> 256 k1."""
+    return (FUSE_DUAL and x.dtype == torch.bfloat16 and _IMPL in (L.IMPL_AUTO, L.IMPL_MFMA)
+            and all(g.kind == "cconv" and g.k == 1 and g.dilation == 1 for g in (g_sc, g3))
+            and (g_sc.cin, g_sc.cout, g3.cin, g3.cout) == (256, 256, 128, 256))
+
+
+def dual_k1_forward(x: Tensor, t_act: Tensor, sc_f: Tensor, sc_b: Tensor, b3_f: Tensor, b3_b: Tensor, post_elu: bool) -> Tensor:
+    """[ELU](W_sc x + W3 t_act + b_sc + b3) in one launch (ga_conv_dual_k1); t_act holds ELU(hidden)."""
+    L.require_cuda(x, t_act, sc_f, b3_f)
+    B, lin, ca = x.shape
+    assert x.is_contiguous() and t_act.is_contiguous() and tuple(t_act.shape) == (B, lin, 128) and ca == 256
+    assert x.dtype == t_act.dtype == sc_f.dtype == b3_f.dtype == torch.bfloat16 and sc_b.dtype == b3_b.dtype == torch.float32
+    y = torch.empty_like(x)
+    p = L.DualK1Params()
+    _fill(p, xa=x.data_ptr(), wa=sc_f.data_ptr(), ba=sc_b.data_ptr(), xb=t_act.data_ptr(), wb=b3_f.data_ptr(), bb=b3_b.data_ptr(),
+          y=y.data_ptr(), rows=B * lin, Ca=256, Cb=128, M=256, post_elu=1 if post_elu else 0)
+    if PROFILE is None:
+        L.check(L.lib().ga_conv_dual_k1(C.byref(p), L.dt(x), L.stream()), "ga_conv_dual_k1")
+        return y
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(L.lib().ga_conv_dual_k1(C.byref(p), L.dt(x), L.stream()), "ga_conv_dual_k1")
+    e1.record()
+    flops = 2.0 * B * lin * 256 * 384
+    PROFILE.append((L.KERNEL_DUAL_K1, flops, e0, e1, (B, 384, 256, 1, lin, 1, 1, 0), flops))
+    return y
+
+
 class ResBlockFrozen(torch.autograd.Function):
     """SEANet residual unit with frozen weights (HF modeling_encodec.py:320-343: shortcut(x) + conv_k1(ELU(conv_k(ELU(x))))) as ONE
     autograd node.  As three ConvFrozen nodes, autograd sums the two gradients that reach x (shortcut and block) with an
@@ -991,6 +1023,15 @@ class ResBlockFrozen(torch.autograd.Function):
             ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
             return y
         ctx.one_launch = False
+        if elu_mid and dual_k1_ok(x, g_sc, g3):
+            # the 256-channel unit: first conv as before (its epilogue writes ELU(t)); shortcut and last conv as one launch over
+            # the concatenated K, the shortcut never written
+            src = x_elu.contiguous() if x_elu is not None else x
+            t = _frozen_forward(g1, src, b1_f, b1_b, ACT_ELU_DONE if x_elu is not None else L.ACT_ELU, post_act=L.ACT_ELU)
+            y = dual_k1_forward(x, t, sc_f, sc_b, b3_f, b3_b, post_elu=elu_out)
+            ctx.geoms, ctx.elu_mid = (g_sc, g1, g3), True
+            ctx.save_for_backward(x, t, sc_d, b1_d, b3_d)
+            return y
         sc = _frozen_forward(g_sc, x, sc_f, sc_b, L.ACT_NONE)
         if x_elu is not None:
             t = _frozen_forward(g1, x_elu.contiguous(), b1_f, b1_b, ACT_ELU_DONE, post_act=L.ACT_ELU if elu_mid else L.ACT_NONE)

@@ -167,6 +167,7 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_STREAM_WIN 13  /* conv_swin_kernel: M <= 64, 2-4 taps, weights in registers, per-wave ring of input windows in LDS */
 #define GA_KERNEL_RESUNIT 14     /* resunit_fwd_kernel (ga_resunit_fwd below; never returned by ga_conv_kernel_id) */
 #define GA_KERNEL_RESUNIT_BWD 15 /* resunit_bwd_kernel (ga_resunit_bwd) */
+#define GA_KERNEL_DUAL_K1 17     /* conv_dual_k1_kernel (ga_conv_dual_k1) */
 #define GA_KERNEL_COOP 16        /* conv_coop_kernel: 256 output channels, K = 2 x 128, many rows: weights in the registers of an
                                     eight-wave workgroup, shared input window (the decoder's transposed conv 128 -> 4 x 64) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
@@ -222,6 +223,26 @@ typedef struct ga_resunit_bwd_params {
     int B, L, C;
 } ga_resunit_bwd_params;
 int ga_resunit_bwd(const ga_resunit_bwd_params* h_params, int dtype, ga_stream_t stream);
+
+/* The closing sum of the 256-channel residual unit in one pass (bf16): y = [ELU]( W_a xa + W_b xb + ba + bb ), row-wise (both convs
+ * are k1): xa [rows][256] = the unit's input with wa = the shortcut's pack [256][256], xb [rows][128] = ELU(hidden) with wb = the
+ * block's last conv's pack [256][128]; y [rows][256].
+ * replaces: shortcut(x) + block[-1](...) of EncodecResnetBlock.forward, HF modeling_encodec.py:333-343 -- two ga_conv launches, the
+ * first one's output written and read back.  Ca = 256, Cb = 128, M = 256 only (GA_ERR_UNSUPPORTED otherwise); no padding, no
+ * item boundaries: rows = B * L. */
+typedef struct ga_dual_k1_params {
+    const void* xa;
+    const void* wa;
+    const float* ba;
+    const void* xb;
+    const void* wb;
+    const float* bb;
+    void* y;
+    long rows;
+    int Ca, Cb, M;
+    int post_elu;
+} ga_dual_k1_params;
+int ga_conv_dual_k1(const ga_dual_k1_params* h_params, int dtype, ga_stream_t stream);
 
 /* weight gradient: dw[m][j][c] += sum_{b,t} g[b][t*g_stride + g_phase][m] * x[b][t*in_stride + j*tap_step + off0][c]
  * fp32 atomics into dw (caller zeroes); dw is in the packed forward layout [M][J][Cin].

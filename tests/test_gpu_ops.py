@@ -1068,6 +1068,33 @@ def test_cooperative_weights_in_registers_kernel_matches_direct_kernel():
             close(y, ref.permute(0, 2, 1), TOL[torch.bfloat16], f"coop vs torch B={B} L={Ln}")
 
 
+def test_dual_source_k1_kernel_matches_two_launches():
+    """ga_conv_dual_k1 (the 256-channel residual unit's closing sum, shortcut 256 -> 256 k1 + last conv 128 -> 256 k1 as one GEMM over
+    the concatenated K, weights in the registers of an eight-wave workgroup) against the two ga_conv launches it replaces
+    (the second with the first as residual, with and without ELU after the sum) and against torch fp32: bf16 accuracy (the
+    one-launch form does not round the shortcut); row counts: less than a tile, ragged last tile, several tiles per workgroup."""
+    torch.manual_seed(47)
+    g_sc, g3 = ConvGeom("cconv", 256, 256, 1), ConvGeom("cconv", 128, 256, 1)
+    wsc = (torch.randn(256, 256, 1) / 16.0).bfloat16().float()
+    w3 = (torch.randn(256, 128, 1) / 11.3).bfloat16().float()
+    bsc, b3 = torch.randn(256) * 0.2, torch.randn(256) * 0.2
+    psc = ops.pack_frozen(g_sc, wsc.to(DEV), None, torch.bfloat16)[0]
+    p3 = ops.pack_frozen(g3, w3.to(DEV), None, torch.bfloat16)[0]
+    for B, Ln in ((1, 7), (3, 1501), (40, 3000)):
+        x = torch.randn(B, Ln, 256).bfloat16()
+        t = F.elu(torch.randn(B, Ln, 128)).bfloat16()
+        assert ops.dual_k1_ok(x.to(DEV), g_sc, g3)
+        for post in (False, True):
+            y1 = ops.dual_k1_forward(x.to(DEV), t.to(DEV), psc, bsc.to(DEV), p3, b3.to(DEV), post).float().cpu()
+            sc = ops.conv_forward(g_sc, x.to(DEV), psc, bsc.to(DEV))
+            y2 = ops.conv_forward(g3, t.to(DEV), p3, b3.to(DEV), res=sc, post_act=L.ACT_ELU if post else 0, act_after_res=post).float().cpu()
+            close(y1, y2, 1e-2, f"dual k1 vs two launches rows={B * Ln} elu={post}")
+            if B * Ln <= 5000:
+                ref = F.conv1d(x.float().permute(0, 2, 1), wsc, bsc) + F.conv1d(t.float().permute(0, 2, 1), w3, b3)
+                ref = (F.elu(ref) if post else ref).permute(0, 2, 1)
+                close(y1, ref, TOL[torch.bfloat16], f"dual k1 vs torch rows={B * Ln} elu={post}")
+
+
 def test_fused_residual_unit_matches_three_node_form():
     """SeanetDecoder's residual units as one autograd node (ops.ResBlockFrozen: the shortcut's data-gradient launch adds the
     block's gradient in its epilogue) against the three-ConvFrozen-node form whose two gradients autograd sums: same forward to
