@@ -731,8 +731,15 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            // (fragments in groups of eight ahead of their MFMAs: left to itself the compiler issues every LDS read right in front
+            // of its MFMA and waits for it -- one LDS round trip per K-step, which is what bounded this kernel)
+            bf16x8 f[8];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[kk], frag(Wl, nt, 2, kk), acc[nt], 0, 0, 0);
+            for (int kk = 0; kk < 8; ++kk) f[kk] = frag(Wl, nt, 2, kk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[kk], f[kk], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         RU_WG_BARRIER();  // the raw window has been read by everyone
 #pragma unroll
@@ -747,7 +754,15 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
 #pragma unroll
             for (int i = 0; i < 16; ++i) ta[i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 24; ++ks) ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], frag(Wl, hn, ks >> 3, ks & 7), ta, 0, 0, 0);
+            for (int tap = 0; tap < 3; ++tap) {
+                bf16x8 f[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) f[kk] = frag(Wl, hn, tap, kk);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[tap * 8 + kk], f[kk], ta, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const ru_f32x4 bb = *(const ru_f32x4*)(b1s + hm * 32 + 8 * q + 4 * h);
@@ -769,11 +784,13 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 tb[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 tb = *(const bf16x8*)(hstage + (nt * 32 + r) * HROW + (ks * 16 + h * 8) * 2);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks], tb, acc[nt], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks) tb[ks] = *(const bf16x8*)(hstage + (nt * 32 + r) * HROW + (ks * 16 + h * 8) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks], tb[ks], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const ru_f32x4 bb = *(const ru_f32x4*)(bsum + wid * 32 + 8 * q + 4 * h);
