@@ -210,6 +210,14 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
             f32x16 ta;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ta[i] = 0.f;
+            // (the bias vectors are read from LDS ahead of the MFMAs that hide the round trip: read where they are used, every
+            // group of exponentials waited for its own LDS read -- the asm stores keep the compiler from hoisting them itself)
+            // (C = 64 has no registers to spare for this: 250 of 256)
+            ru_f32x4 bb1[H / 8];
+            if (MT == 1) {
+#pragma unroll
+                for (int q = 0; q < H / 8; ++q) bb1[q] = *(const ru_f32x4*)(b1s + 8 * q + 4 * h);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const bf16x8 xb = *(const bf16x8*)(Wl + foff[nt % NTB][ks] + (nt / NTB) * 4096);
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
             }
 #pragma unroll
             for (int q = 0; q < H / 8; ++q) {  // accumulator (q, i) of lane (r, h): hidden channel 8q + 4h + i of step r
-                const ru_f32x4 bb = *(const ru_f32x4*)(b1s + 8 * q + 4 * h);
+                const ru_f32x4 bb = MT == 1 ? bb1[q] : *(const ru_f32x4*)(b1s + 8 * q + 4 * h);
                 u32x2 o;
                 o.x = sw_elu2(sw_pack_bf16(ta[4 * q] + bb[0], ta[4 * q + 1] + bb[1]));
                 o.y = sw_elu2(sw_pack_bf16(ta[4 * q + 2] + bb[2], ta[4 * q + 3] + bb[3]));
@@ -225,6 +233,12 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
             }
             __builtin_amdgcn_wave_barrier();
             // 3b. second conv onto the shortcut
+            constexpr bool EARLY = !TAIL && MT == 1;  // (C = 64 has no registers to spare: its vectors are read per 32 channels below)
+            ru_f32x4 bbs[4];
+            if (EARLY) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bbs[q] = *(const ru_f32x4*)(bsum + 8 * q + 4 * h);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS3; ++ks) {
                 const bf16x8 tb = *(const bf16x8*)(stage + r * TROW + (ks * 16 + h * 8) * 2);
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const ru_f32x4 bb = *(const ru_f32x4*)(bsum + mt * 32 + 8 * q + 4 * h);
+                    const ru_f32x4 bb = EARLY ? bbs[q] : *(const ru_f32x4*)(bsum + mt * 32 + 8 * q + 4 * h);
                     u32x2 o;
                     o.x = sw_pack_bf16(acc[nt][mt][4 * q] + bb[0], acc[nt][mt][4 * q + 1] + bb[1]);
                     o.y = sw_pack_bf16(acc[nt][mt][4 * q + 2] + bb[2], acc[nt][mt][4 * q + 3] + bb[3]);
@@ -269,11 +283,14 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
         }
         if (TAIL) {
             // every read of the input window is done: ELU(y) takes its place (row w of the window = row tl0 + w of the item)
+            ru_f32x4 bby[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bby[q] = *(const ru_f32x4*)(bsum + 8 * q + 4 * h);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const ru_f32x4 bb = *(const ru_f32x4*)(bsum + 8 * q + 4 * h);
+                    const ru_f32x4 bb = bby[q];
                     u32x2 o;
                     o.x = sw_elu2(sw_pack_bf16(acc[nt][0][4 * q] + bb[0], acc[nt][0][4 * q + 1] + bb[1]));
                     o.y = sw_elu2(sw_pack_bf16(acc[nt][0][4 * q + 2] + bb[2], acc[nt][0][4 * q + 3] + bb[3]));
@@ -753,6 +770,9 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
             f32x16 ta;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ta[i] = 0.f;
+            ru_f32x4 bbh[4];  // (read ahead of the MFMAs that hide the LDS round trip)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bbh[q] = *(const ru_f32x4*)(b1s + hm * 32 + 8 * q + 4 * h);
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 bf16x8 f[8];
@@ -765,7 +785,7 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const ru_f32x4 bb = *(const ru_f32x4*)(b1s + hm * 32 + 8 * q + 4 * h);
+                const ru_f32x4 bb = bbh[q];
                 u32x2 o;
                 o.x = sw_elu2(sw_pack_bf16(ta[4 * q] + bb[0], ta[4 * q + 1] + bb[1]));
                 o.y = sw_elu2(sw_pack_bf16(ta[4 * q + 2] + bb[2], ta[4 * q + 3] + bb[3]));
@@ -785,6 +805,9 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             bf16x8 tb[4];
+            ru_f32x4 bbo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bbo[q] = *(const ru_f32x4*)(bsum + wid * 32 + 8 * q + 4 * h);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) tb[ks] = *(const bf16x8*)(hstage + (nt * 32 + r) * HROW + (ks * 16 + h * 8) * 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -793,7 +816,7 @@ __global__ __launch_bounds__(256) void resunit_wide_fwd_kernel(ga_resunit_params
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const ru_f32x4 bb = *(const ru_f32x4*)(bsum + wid * 32 + 8 * q + 4 * h);
+                const ru_f32x4 bb = bbo[q];
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
