@@ -152,12 +152,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_swin_kernel(ConvParams p, int t
         const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NR;
 
         if (elu) {  // once per element, in place (each lane the chunks it loaded)
-#pragma unroll
-            for (int i = 0; i < NLW; ++i)
-                if ((i + 1) * 64 <= WCH || lane < WCH - i * 64) {
-                    char* const q = Wl + (i * 64 + lane) * 16;
-                    sw_lds_write16(q, sw_elu8(*(const u32x4*)q));
-                }
+            sw_elu_window<NLW, WCH, 3>(Wl, lane);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
@@ -308,12 +303,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_swin1_kernel(ConvParams p, int 
         char* const Wl = ring + (it % RD) * SLOT;
         const int b = t / tiles_per_item, tl0 = (t - b * tiles_per_item) * NR;
         if (elu) {
-#pragma unroll
-            for (int i = 0; i < NLW; ++i)
-                if ((i + 1) * 64 <= WCH || lane < WCH - i * 64) {
-                    char* const q = Wl + (i * 64 + lane) * 16;
-                    sw_lds_write16(q, sw_elu8(*(const u32x4*)q));
-                }
+            sw_elu_window<NLW, WCH, 1>(Wl, lane);  // (sixteen waves per CU: 128 registers, none to spare for reading ahead)
             __builtin_amdgcn_wave_barrier();
         }
         sw_f32x4 acc[4];

@@ -196,12 +196,7 @@ __global__ __launch_bounds__(WPB * 64) void resunit_fwd_kernel(ga_resunit_params
         }
         __builtin_amdgcn_wave_barrier();
         // 2. ELU once per element, in place (each lane the chunks it loaded)
-#pragma unroll
-        for (int i = 0; i < NLW; ++i)
-            if ((i + 1) * 64 <= WCH || lane < WCH - i * 64) {
-                char* const q = Wl + (i * 64 + lane) * 16;
-                sw_lds_write16(q, sw_elu8(*(const u32x4*)q));
-            }
+        sw_elu_window<NLW, WCH, MT == 1 ? 3 : 1>(Wl, lane);
         __builtin_amdgcn_wave_barrier();
 
 #pragma unroll

@@ -63,3 +63,23 @@ __device__ __forceinline__ u32x4 sw_elu8(u32x4 in) {
     for (int i = 0; i < 4; ++i) out[i] = sw_elu2(in[i]);
     return out;
 }
+
+// In-place ELU over the chunks a lane loaded into a window (chunk i of the lane at byte (i*64 + lane)*16; the last of the NLW
+// chunks exists for lane < WCH - (NLW-1)*64 only), EG chunks read ahead of their exponentials: one chunk at a time, every read
+// is waited for before its eight exponentials start (the asm stores pin the order), an LDS round trip per chunk.  Reads past the
+// window's last chunk stay inside the wave's LDS (the slot is followed by another slot or the stage) and are not written back.
+template <int NLW, int WCH, int EG>
+__device__ __forceinline__ void sw_elu_window(char* Wl, int lane) {
+#pragma unroll
+    for (int i0 = 0; i0 < NLW; i0 += EG) {
+        u32x4 v[EG];
+#pragma unroll
+        for (int j = 0; j < EG; ++j)
+            if (i0 + j < NLW) v[j] = *(const u32x4*)(Wl + ((i0 + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < EG; ++j) {
+            const int i = i0 + j;
+            if (i < NLW && ((i + 1) * 64 <= WCH || lane < WCH - i * 64)) sw_lds_write16(Wl + (i * 64 + lane) * 16, sw_elu8(v[j]));
+        }
+    }
+}
