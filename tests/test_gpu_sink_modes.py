@@ -51,6 +51,14 @@ def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
         err = float((ga - gb).abs().max() / gb.abs().max())
         assert err <= 1e-5, (name, err)
     # ... and so do the parameters after the step, up to what AdamW's first step (lr * g / (|g| + eps)) makes of that noise
-    for pa, pb, name in ((a[0], b[0], "G"), (a[1], b[1], "D")):
-        err = float((pa - pb).abs().max() / pb.abs().max())
+    # AdamW's first step is lr * g / (|g| + 1e-8): where an entry's gradient is itself of the size of the summation noise (a few
+    # 1e-9 here) the two paths may step in different directions -- by at most 2 lr, and that is all that can be asked of those
+    # entries (this bound, applied to every entry at 1e-4 of max|p|, is the likely cause of two failures in some twenty-five full-suite runs, never reproduced alone); entries
+    # whose gradient stands clear of the noise must agree
+    for pa, pb, ga, gb, name in ((a[0], b[0], a[5], b[5], "G"), (a[1], b[1], a[6], b[6], "D")):
+        diff = (pa - pb).abs()
+        assert float(diff.max()) <= 2.1e-3, (name, float(diff.max()))
+        clear = gb.abs() >= 1e-3 * gb.abs().max()
+        assert int(clear.sum()) > 0.2 * clear.numel()
+        err = float(diff[clear].max() / pb.abs().max())
         assert err <= 1e-4, (name, err)
