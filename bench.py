@@ -102,7 +102,7 @@ def cpu_baseline(T: int, batches=(4, 12), iters: int = 5, budget_s: float = 75.0
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
-    scratch/pmc_traffic.py from two rocprofv3 --pmc passes over this same command: FETCH_SIZE x2 and WRITE_SIZE, both KiB, as
+    tools/pmc_traffic.py from two rocprofv3 --pmc passes over this same command: FETCH_SIZE x2 and WRITE_SIZE, both KiB, as
     MI355X_MICROARCH.md's HBM section prescribes).  PMC counters cannot be read from inside the process, so the figure is
     the last profiled build's; `traffic_source` names the file."""
     import glob
@@ -118,7 +118,7 @@ def pmc_traffic(kernel_name):
         return {}
     out = {"traffic": round(k["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
            "traffic_source": "profiles/" + os.path.basename(files[-1])}
-    # MFMA utilisation of the same kernels from the newest committed counter pass (scratch/pmc_mfma.py:
+    # MFMA utilisation of the same kernels from the newest committed counter pass (tools/pmc_mfma.py:
     # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs))
     mf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
     if mf:
@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--stft-stress", action="store_true", help="BASELINE config 5: the six MR-STFT resolutions (256 ... 8192) of SURVEY.md "
                     "8(d); use with --frames 2250 (30 s clips, S = 720000) and a batch sized for the 288 GB of HBM")
+    ap.add_argument("--no-fp32-batch12", action="store_true", help="skip the fp32-mode leg (B=12, the rtol-1e-4 parity path) reported under 'fp32_batch12'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
@@ -197,31 +198,38 @@ def main():
         dp.broadcast_params(opt_g, opt_d)
     gen = torch.Generator().manual_seed(328 + rank)
 
-    state = {"batches": None, "i": 0}
+    state = {"batches": None, "i": 0, "models": (G, D, codec, opt_g, opt_d)}
 
     def step(_i=None):
         i = state["i"]
         state["i"] += 1
         batches = state["batches"]
         b = batches[i % len(batches)]
-        return codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
+        G_, D_, codec_, og_, od_ = state["models"]
+        return codec_train_iteration(scfg, G_, D_, codec_, og_, od_, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
 
     def barrier():
         if dp is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def measure(batch):
+    def measure(batch, steps=None, warmup=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         state["batches"] = [make_batch(batch, args.frames, device, gen) for _ in range(2)]
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             out = step()
+            if dp is not None:
+                dp.check_first_overlapped_iteration(device)  # (once: RCCL kernels beside the persistent LSTM, gan_amd/dp.py)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             out = step()
         barrier()
         el = time.perf_counter() - t0
+        if ops.lstm_persist_error(device):  # sticky: any persistent LSTM launch since the last look
+            raise SystemExit("a persistent LSTM launch of the frozen decoder ran out of its bounded wait: the timed steps are invalid")
         if dp is not None:
             t = torch.tensor([el], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -230,6 +238,23 @@ def main():
         assert lg == lg, "loss is NaN"
         return el, lg
 
+    # fp32 mode (the rtol-1e-4 parity path: exact fp32 FMA convolutions) at the reference's default batch, BASELINE.md section 3
+    # asks for both precisions; a short leg on its own models, freed before the headline measurement
+    fp32_b12 = None
+    if args.precision == "bf16" and not args.no_fp32_batch12 and args.frames <= 375 and not args.stft_stress:
+        G32, D32, codec32 = make_models("fp32", device, seed=328)
+        og32 = FusedAdamW(G32.parameters(), lr=scfg.lr_g, betas=scfg.betas)
+        od32 = FusedAdamW(D32.parameters(), lr=scfg.lr_d, betas=scfg.betas)
+        if dp is not None:
+            dp.broadcast_params(og32, od32)
+        state["models"] = (G32, D32, codec32, og32, od32)
+        n32 = max(2, min(4, args.steps))
+        el32, _ = measure(12, steps=n32, warmup=1)
+        fp32_b12 = {"batch_per_gpu": 12, "global_batch": 12 * world, "dtype": "fp32", "value": round(12 * world * n32 / el32, 3),
+                    "unit": "samples/s", "ms_per_step": round(1e3 * el32 / n32, 3), "steps": n32, "warmup": 1}
+        state["models"] = (G, D, codec, opt_g, opt_d)
+        del G32, D32, codec32, og32, od32
+        torch.cuda.empty_cache()
     batch12 = None
     if args.batch != 12 and not args.no_batch12:  # the reference's default batch size, second line of the report
         el12, _ = measure(12)
@@ -302,6 +327,10 @@ def main():
         }
         if batch12 is not None:
             line["batch12"] = batch12
+        if fp32_b12 is not None:
+            line["fp32_batch12"] = fp32_b12
+        line["config"]["note"] = ("headline batch is 64 per GPU since round 2 (round 1's BENCH line was B=12): compare rounds on "
+                                  "'batch12', the reference's default batch, which every run reports")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.frames, (4, 12), args.cpu_iters, args.cpu_budget_s)
         sys.stdout.flush()

@@ -18,7 +18,7 @@
 //     ds_read_b128 group hit 16 different slots.
 //   * epilogue: bias and activation on the accumulators, bf16 rows through a wave-private LDS stage, 16-byte row-contiguous stores
 // The K order (tap-major, then channel), the accumulation chain and the rounding points are those of conv_stream_kernel:
-// results are bit-identical (scratch/swin_check.py, tests/test_gpu_ops.py).
+// results are bit-identical (tools/swin_check.py, tests/test_gpu_ops.py).
 #include "swin_common.h"
 #include <stdlib.h>
 

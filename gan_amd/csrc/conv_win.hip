@@ -266,7 +266,7 @@ int ga_conv_win_wanted(const ConvParams& p) {
     if (p.J * p.Cin < 512 || p.Lout < 2 * CW_BN) return 0;            // short K / short items: the gathered kernel's ground
     const long tiles = (long)p.B * ((p.Lout + CW_BN - 1) / CW_BN) * ((p.M + (kind == 1 ? 63 : 127)) / (kind == 1 ? 64 : 128));
     if (tiles < 1024) return 0;                                        // two workgroups per CU, a few rounds
-    // measured at B = 128 (scratch/win_check.py), two-stage weight ring: the stride-4 form 788-840 TFLOP/s against 514-550 for the
+    // measured at B = 128 (tools/win_check.py), two-stage weight ring: the stride-4 form 788-840 TFLOP/s against 514-550 for the
     // gathered kernel on D blocks.1 forward; the stride-1 form 625-630 against 520-540 on its folded data gradient (with the
     // three-stage ring, two workgroups per CU, it only tied).  GA_CONV_WIN=1 keeps the stride-1 form off, 0 both.
     return (kind == 1 || mode >= 2) ? kind : 0;

@@ -32,24 +32,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define LP_W1_STRIDE 1040  // bytes per LDS row of W1 (512 bf16 + 16: the 16 rows of an MFMA tile spread over the banks)
 #define LP_W2_STRIDE 2064
 #define LP_SPIN_LIMIT (1 << 22)
-#define LP_WS_HEADER 1024  // bytes: error word at 0, counter of group g at 128 + 128*g
+#define LP_WS_HEADER 1024  // bytes: STICKY error word at 0 (never cleared by a launch: only the host clears it after reading it),
+                           // this launch's abort word at 64, counter of group g at 128 + 128*g; a launch clears bytes 64 .. 1023
+#define LP_WS_STICKY 64    // bytes in front of the per-launch part
 
 __device__ __forceinline__ float lp_sigm(float v) { return 1.f / (1.f + __expf(-v)); }
 
 struct LstmPersistWs {
-    unsigned* err;
+    unsigned* err;   // this launch's abort word (cleared before every launch): lets the other workgroups stop waiting early
+    unsigned* sticky;  // raised together with it and left standing, so that a timeout in ANY launch since the host last looked is seen
     unsigned* cnt;   // this launch's counters (stride 32 words)
     char* hx;        // [groups][2 parity][2 layer][64 wg][NB][8] bf16
 };
 
 // wait until the group's counter reaches `target`; false once the launch is known to be broken
-__device__ __forceinline__ bool lp_wait(unsigned* cnt, unsigned* err, unsigned target, bool dead) {
+__device__ __forceinline__ bool lp_wait(unsigned* cnt, unsigned* err, unsigned* sticky, unsigned target, bool dead) {
     if (dead) return true;
     int spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > LP_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
     }
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // ---- wait for every workgroup's publication of step s-1
         if (s > 0) {
-            if (tid == 0 && lp_wait(cnt, ws.err, (unsigned)(LP_WG_PER_GROUP * s), dead)) dead_s = 1;
+            if (tid == 0 && lp_wait(cnt, ws.err, ws.sticky, (unsigned)(LP_WG_PER_GROUP * s), dead)) dead_s = 1;
             __syncthreads();
             dead = dead_s != 0;
         }
@@ -309,9 +313,10 @@ int ga_lstm_fwd_persist(const ga_lstm_params& p, hipStream_t s) {
     for (int b_first = 0; b_first < p.B;) {
         int groups, nbt;
         lp_shape(p.B - b_first, cus, groups, nbt);
-        if (hipMemsetAsync(p.ws, 0, LP_WS_HEADER, s) != hipSuccess) return GA_ERR_LAUNCH;
+        if (hipMemsetAsync((char*)p.ws + LP_WS_STICKY, 0, LP_WS_HEADER - LP_WS_STICKY, s) != hipSuccess) return GA_ERR_LAUNCH;
         LstmPersistWs ws;
-        ws.err = (unsigned*)p.ws;
+        ws.err = (unsigned*)p.ws + LP_WS_STICKY / 4;
+        ws.sticky = (unsigned*)p.ws;
         ws.cnt = (unsigned*)p.ws + 32;
         ws.hx = (char*)p.ws + LP_WS_HEADER;
         const size_t lds = lp_lds_bytes(nbt);
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         if (s > 0) {
-            if (tid == 0 && lp_wait(cnt, ws.err, (unsigned)(LP_WG_PER_GROUP * s), dead)) dead_s = 1;
+            if (tid == 0 && lp_wait(cnt, ws.err, ws.sticky, (unsigned)(LP_WG_PER_GROUP * s), dead)) dead_s = 1;
             __syncthreads();
             dead = dead_s != 0;
         }
@@ -535,9 +540,10 @@ int ga_lstm_bwd_persist(const ga_lstm_bwd_params& p, hipStream_t s) {
     for (int b_first = 0; b_first < p.B;) {
         int groups, nbt;
         lp_shape(p.B - b_first, cus, groups, nbt);
-        if (hipMemsetAsync(p.ws, 0, LP_WS_HEADER, s) != hipSuccess) return GA_ERR_LAUNCH;
+        if (hipMemsetAsync((char*)p.ws + LP_WS_STICKY, 0, LP_WS_HEADER - LP_WS_STICKY, s) != hipSuccess) return GA_ERR_LAUNCH;
         LstmPersistWs ws;
-        ws.err = (unsigned*)p.ws;
+        ws.err = (unsigned*)p.ws + LP_WS_STICKY / 4;
+        ws.sticky = (unsigned*)p.ws;
         ws.cnt = (unsigned*)p.ws + 32;
         ws.hx = (char*)p.ws + LP_WS_HEADER;
         const size_t lds = lp_bwd_lds_bytes(nbt);

@@ -4,7 +4,7 @@ MI355X-side design:
 
   * the batch is sharded across ranks; G, D, decoder and both optimizers are replicated;
   * gradients live in the optimizer's flat fp32 buffer (gan_amd/optim.py) and are SUM-all-reduced in contiguous
-    buckets (default 64 MiB: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large messages beat many
+    buckets (default 24 MiB, closed at parameter boundaries: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large messages beat many
     small ones); 1/world_size is folded into the fused AdamW kernel (grad_scale), so no separate scaling pass;
   * buckets are issued asynchronously in reverse parameter order (the order backward produces them) and waited for
     only right before the clip+AdamW kernel;
@@ -169,7 +169,43 @@ class DataParallel:
         # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward): the default as soon
         # as there is more than one rank (north star: "all-reduce overlapped with the discriminator backward pass").  With one
         # rank there is nothing to hide, and the side-stream collectives only cost launches.
+        # NOT YET VALIDATED ON MORE THAN ONE GPU: no multi-GPU node was available in rounds 1-3 (SCALE_r0*.json: skipped), so this
+        # default rests on the gloo world-2 CPU tests and the forced one-rank RCCL test.  What runs concurrently on hardware is
+        # RCCL's comm-stream kernels beside the persistent LSTM backward, which needs one workgroup resident on every CU; its
+        # bounded waits turn a lost residency into an error word, and check_first_overlapped_iteration() below reads it after the
+        # first overlapped iteration so a bad co-residency is reported at once instead of at the end of the epoch.
+        # `bench.py --no-dp-overlap` / DataParallel.overlap = False select the after-backward all-reduce.
         self.overlap = self.world_size > 1
+        self._overlap_checked = False
+
+    def check_first_overlapped_iteration(self, device) -> None:
+        """Once, after the first iteration that overlapped collectives with the backward pass: a persistent LSTM launch that lost
+        its residency to a co-running RCCL kernel has raised the sticky error word (gan_amd.ops.lstm_persist_error)."""
+        if self._overlap_checked or not self.overlap:
+            return
+        self._overlap_checked = True
+        from . import ops
+        if torch.device(device).type == "cuda" and ops.lstm_persist_error(device):
+            raise RuntimeError("a persistent LSTM launch ran out of its bounded wait while gradient all-reduces were overlapped with "
+                               "the backward pass: set DataParallel.overlap = False (bench.py --no-dp-overlap) or "
+                               "gan_amd.ops.LSTM_PERSIST = False")
+
+    def reduce_history_means(self, host: dict, counts: dict) -> None:
+        """Per-epoch loss sums and their iteration counts summed over the ranks, in place (the history row is then the mean over
+        the GLOBAL batch, the same on every rank, instead of rank 0's shard only)."""
+        if self.world_size == 1:
+            return
+        keys = sorted(host)
+        ckeys = sorted(counts)
+        t = torch.tensor([float(host[k]) for k in keys] + [float(counts[k]) for k in ckeys], dtype=torch.float64)
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = t.to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        vals = t.cpu().tolist()
+        for k, v in zip(keys, vals[:len(keys)]):
+            host[k] = v
+        for k, v in zip(ckeys, vals[len(keys):]):
+            counts[k] = v
 
     def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
         """Contiguous [start, end) slices of the flat gradient buffer, last parameters first."""

@@ -92,7 +92,10 @@ class Lab1WaveAdapter:
         power = spec.real ** 2 + spec.imag ** 2                            # [B, 513, frames]
         mel = torch.matmul(power.transpose(-1, -2), self.fb).transpose(-1, -2).clamp_min(1e-8)
         mel_db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
-        mel_db = torch.max(mel_db, (mel_db.detach().amax() - 80.0))       # top_db over the whole batch tensor (see module doc)
+        # top_db over the whole batch tensor (see module doc).  The floor is NOT detached: torchaudio's amplitude_to_DB takes
+        # torch.max(x_db, x_db.amax() - top_db) with the graph attached, so every bin clamped to the floor sends its upstream
+        # gradient to the peak bin (checked by a finite-difference CPU test)
+        mel_db = torch.max(mel_db, (mel_db.amax() - 80.0))
         t = int(mel_db.shape[-1])
         if t > self.n_frames:
             start = (t - self.n_frames) // 2

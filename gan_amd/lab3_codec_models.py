@@ -286,6 +286,8 @@ def feature_matching_loss(real_feats: Sequence[torch.Tensor], fake_feats: Sequen
     # F.l1_loss(a.detach(), b): the gradient goes to the fake features only; 1/numel is applied inside the reduction kernel
     terms = [ops.reduce_sum(b, a.detach(), L.RED_ABSDIFF, 1.0 / b.numel()) for a, b in zip(real_feats, fake_feats)]
     if not terms:
+        # no feature maps, hence no device to put a result on: the reference returns the Python float 0.0 here (:181-186,
+        # `loss = 0.0` divided by max(1, 0)); a 0-dim CPU zero behaves the same in the caller's weighted sum
         return torch.zeros(())
     return torch.stack(terms).sum() / max(1, len(fake_feats))
 

@@ -539,14 +539,25 @@ def train_codec_stage(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTr
             for k in keys:
                 if k in res:
                     acc[k] += res[k].reshape(())
-        n = max(1, n_batches)
+            if dp is not None:
+                dp.check_first_overlapped_iteration(device)
         host = {k: float(v) for k, v in acc.items()}  # one sync per epoch
+        if dp is not None:
+            # history rows are means over the GLOBAL batch: sums and iteration counts are summed over the ranks (every rank takes
+            # the same number of iterations, so n_batches * world is the divisor) -- the step counters stay per-rank figures
+            counts = {"n": float(n_batches), "d": float(d_steps_taken)}
+            dp.reduce_history_means(host, counts)
+            n = max(1.0, counts["n"])
+            d_div = max(1.0, counts["d"])
+        else:
+            n = max(1, n_batches)
+            d_div = max(1, d_steps_taken)
         if device.type == "cuda" and ops.lstm_persist_error(device):
             raise RuntimeError("a persistent LSTM launch of the frozen decoder ran out of its bounded wait (lstm_persist.hip): its "
                                "workgroups were not all resident; this epoch's results are invalid (set gan_amd.ops.LSTM_PERSIST = False)")
         row = {
             "stage": str(stage_cfg.stage_name), "epoch": int(epoch), "loss_g": host["loss_g"] / n,
-            "loss_d": (host["loss_d"] / max(1, d_steps_taken)) if d_steps_taken > 0 else 0.0,
+            "loss_d": (host["loss_d"] / d_div) if d_steps_taken > 0 else 0.0,
             "loss_adv": host["loss_adv"] / n, "loss_feature_match": host["loss_fm"] / n,
             "loss_latent_l1": host["loss_lat_l1"] / n, "loss_continuity": host["loss_lat_cont"] / n,
             "loss_content": host["loss_content"] / n, "loss_style": host["loss_style"] / n,

@@ -207,7 +207,7 @@ def _fold_phases(p: L.ConvParams, x: Tensor, bias):
 MERGE_PHASES = True  # tests switch this off to compare against the phase-by-phase launches
 _IMPL = L.IMPL_AUTO
 WGRAD_SLABS = False  # True: per-slice slabs + a reduce kernel instead of fp32 atomics on dw (measured no faster; tests run both)
-FORCE_KSPLIT = None  # tuning aid (scratch/bench_conv.py): this split for every gathered-GEMM launch
+FORCE_KSPLIT = None  # tuning aid (tools/bench_conv.py): this split for every gathered-GEMM launch
 SPLIT_K = True  # tests switch this off to compare split-K against the single-pass kernel
 PROFILE = None  # set to a list by bench.py to collect (kernel id, launched flops, start event, end event)
 
@@ -1460,9 +1460,19 @@ def _lstm_workspace(device) -> Tensor:
     return ws
 
 
-def lstm_persist_error(device=None) -> bool:
-    """True when a persistent LSTM launch on this device raised its error word (a bounded wait ran out).  Synchronises."""
-    return any(bool(ws[:4].view(torch.int32).item()) for (d, _), ws in _LSTM_WS.items() if device is None or d == torch.device(device))
+def lstm_persist_error(device=None, clear: bool = True) -> bool:
+    """True when ANY persistent LSTM launch on this device since the last cleared report raised the error word (a bounded wait
+    ran out: that launch's y / dg1 are invalid).  The word is sticky on the device side -- launches clear only their own abort
+    word and counters -- so a timeout in an early launch of an epoch is still seen here.  Synchronises; `clear` re-arms it."""
+    hit = False
+    for (d, _), ws in _LSTM_WS.items():
+        if device is not None and d != torch.device(device):
+            continue
+        if bool(ws[:4].view(torch.int32).item()):
+            hit = True
+            if clear:
+                ws[:4].zero_()
+    return hit
 
 
 class LstmSkip(torch.autograd.Function):

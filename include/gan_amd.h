@@ -50,7 +50,10 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
 #define GA_IMPL_AUTO 0   /* MFMA for bf16 when the shape fills tiles, else direct */
 #define GA_IMPL_DIRECT 1 /* vector-ALU fp32 FMA chains (exact fp32 mode, thin layers) */
 #define GA_IMPL_MFMA 2   /* bf16 MFMA implicit GEMM (gathered-GEMM kernel when it applies, else the window kernel); error if unsupported */
-#define GA_IMPL_MFMA_WINDOW 3 /* force the LDS-window MFMA kernel (conv_mfma_kernel) */
+#define GA_IMPL_MFMA_WINDOW 3 /* force the older LDS-window MFMA kernels (conv_mfma_kernel / wgrad_mfma_kernel).  TEST CROSS-CHECK: they are
+                                 compiled in so the tests can compare the product kernels against an independent implementation;
+                                 GA_IMPL_AUTO reaches conv_mfma_kernel only for shapes the gathered kernel refuses (ELU on load with
+                                 fp32 output, M % 8 != 0) and never reaches wgrad_mfma_kernel */
 #define GA_IMPL_MFMA_PP 4     /* force the ping-pong gathered-GEMM kernel (conv_pp_kernel: 256x256 tiles, eight waves); error if
                                  unsupported.  AUTO / MFMA pick it by themselves for deep-K layers with >= 192 output channels */
 
@@ -211,7 +214,8 @@ int ga_resunit_fwd(const ga_resunit_params* h_params, int dtype, ga_stream_t str
  *     gt = (W3^T gy) * ELU'(hidden)          ELU' taken from t_act = ELU(hidden), as GA_DACT_ELU_FROM_OUT
  *     gx = W_sc^T gy + (conv_k3^T gt, with the rows of the reflected left pad folded back) * ELU'(x)
  * replaces the unit's three data-gradient ga_conv launches and the pad fix-up launch.  Weights in ga_conv's data-gradient
- * layout (GA_PACK_CONV_DGRAD_S1): w_sc_d [C][1][C], w1_d [C][3][C/2], w3_d [C/2][1][C].  Same shape limits as ga_resunit_fwd. */
+ * layout (GA_PACK_CONV_DGRAD_S1): w_sc_d [C][1][C], w1_d [C][3][C/2], w3_d [C/2][1][C].  C in {32, 64} only (the 128-channel unit's
+ * backward returns GA_ERR_UNSUPPORTED: its data gradient runs as three ga_conv launches); other limits as ga_resunit_fwd. */
 typedef struct ga_resunit_bwd_params {
     const void* gy;
     const void* t_act;
@@ -431,8 +435,10 @@ typedef struct ga_lstm_params {
     void* ws;        /* optional (bf16, H = 512): workspace of ga_lstm_persist_workspace_bytes() bytes, 256-byte aligned.  With
                         it the pass runs as ONE persistent launch (lstm_persist.hip: recurrent weights resident in LDS, hidden
                         state exchanged between workgroups through ws with write-through stores and a counter) instead of T+1
-                        step launches; h1 / h2 / c1 / c2 are then not written.  The first word of ws is an error flag the
-                        kernel raises when a bounded wait ran out (results invalid); calls sharing one ws must not overlap. */
+                        step launches; h1 / h2 / c1 / c2 are then not written.  The first word of ws is a STICKY error flag
+                        a kernel raises when a bounded wait ran out (results of that launch invalid): the caller zeroes ws once
+                        when it allocates it, no launch ever clears that word (a launch clears bytes 64 .. 1023 only), so the
+                        flag covers every launch since the caller last read and cleared it; calls sharing one ws must not overlap. */
     size_t ws_bytes;
 } ga_lstm_params;
 int ga_lstm_fwd(const ga_lstm_params* h_params, ga_stream_t stream);

@@ -18,3 +18,10 @@ def golden():
     """Vectors produced by the reference itself (tests/golden/make_golden.py)."""
     with np.load(REPO / "tests" / "golden" / "codec_golden.npz") as z:
         return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def fullgrad_golden():
+    """Full-shape (B=2, T=375) gradient vectors produced by the reference itself (tests/golden/make_golden_fullgrad.py)."""
+    with np.load(REPO / "tests" / "golden" / "fullgrad_golden.npz") as z:
+        return {k: z[k] for k in z.files}

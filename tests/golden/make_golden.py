@@ -93,8 +93,9 @@ def grads_summary(mod) -> dict:
 
 
 # ----------------------------------------------------------------------------------------------
-def ref_iteration(G, D, dec, opt_g, opt_d, batch, global_step, cfg, record):
-    """Mirror of lab3_codec_train.py:404-591 for the north-star loss subset."""
+def ref_iteration(G, D, dec, opt_g, opt_d, batch, global_step, cfg, record, grad_hook=None):
+    """Mirror of lab3_codec_train.py:404-591 for the north-star loss subset.
+    `grad_hook(kind, module)` (optional) runs right after each backward pass, before the clip."""
     q_src, zc_src, z_style_tgt, noise, q_real_tgt, q_real_tgt_g = batch
     q_hat = G(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
               style_dropout_p=0.0, style_jitter_std=0.0)
@@ -127,6 +128,8 @@ def ref_iteration(G, D, dec, opt_g, opt_d, batch, global_step, cfg, record):
         loss_d.backward()
         if record:
             out["d_grads"] = grads_summary(D)
+        if grad_hook is not None:
+            grad_hook("d", D)
         if float(cfg["d_grad_clip_norm"]) > 0.0:
             gn = torch.nn.utils.clip_grad_norm_(D.parameters(), float(cfg["d_grad_clip_norm"]))
             out["d_grad_norm"] = float(gn)
@@ -153,6 +156,8 @@ def ref_iteration(G, D, dec, opt_g, opt_d, batch, global_step, cfg, record):
     loss_g.backward()
     if record:
         out["g_grads"] = grads_summary(G)
+    if grad_hook is not None:
+        grad_hook("g", G)
     if float(cfg["g_grad_clip_norm"]) > 0.0:
         gn = torch.nn.utils.clip_grad_norm_(G.parameters(), float(cfg["g_grad_clip_norm"]))
         out["g_grad_norm"] = float(gn)

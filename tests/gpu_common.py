@@ -38,3 +38,23 @@ def run_gpu_iteration(G, D, codec, batch, cfg, global_step, opt_g=None, opt_d=No
     out = codec_train_iteration(scfg, G, D, codec, opt_g, opt_d, q_src, zc, zs, noise, q_real_d, q_real_g, global_step)
     out["opt_g"], out["opt_d"] = opt_g, opt_d
     return out
+
+
+def grab_flat_grads(opts: dict) -> dict:
+    """Wrap each FusedAdamW.step so the flat gradient buffer, as the optimizer sees it right before its update (after the
+    all-reduce, before the clip), is kept: returns the dict the copies land in."""
+    grabbed = {}
+    for name, opt in opts.items():
+        orig = opt.step
+
+        def step(grads_gathered=False, _o=orig, _opt=opt, _n=name):
+            grabbed[_n] = _opt.flat_g.detach().clone()
+            return _o(grads_gathered=grads_gathered)
+        opt.step = step
+    return grabbed
+
+
+def flat_in_named_order(mod, opt, flat: torch.Tensor) -> torch.Tensor:
+    """The optimizer's flat buffer re-ordered as torch.cat over mod.named_parameters() (the order the fixtures use)."""
+    by_id = {id(p): (off, p.numel()) for p, off in zip(opt.params, opt.offsets)}
+    return torch.cat([flat[by_id[id(p)][0]:by_id[id(p)][0] + by_id[id(p)][1]] for _, p in mod.named_parameters() if p.requires_grad])

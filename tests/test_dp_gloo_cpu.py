@@ -101,6 +101,12 @@ def _worker(rank, world, port, q):
         full = torch.sqrt(((my - fx) ** 2).sum()) / (torch.sqrt((my ** 2).sum()) + 1e-8) + (fx.log() - my.log()).abs().mean()
         full.backward()
         assert torch.allclose(lx.grad, world * fx.grad[sl], rtol=1e-4, atol=1e-8)
+        # per-epoch history: loss sums and iteration counts are summed over the ranks, so the row is the global-batch mean
+        host, counts = {"loss_g": 3.0 * (rank + 1), "loss_d": 1.0 + rank}, {"n": 4.0, "d": 2.0}
+        dp.reduce_history_means(host, counts)
+        assert host == {"loss_g": 9.0, "loss_d": 3.0} and counts == {"n": 8.0, "d": 4.0}
+        dp.check_first_overlapped_iteration("cpu")  # (CPU: nothing to read; must be a no-op the second time too)
+        dp.check_first_overlapped_iteration("cpu")
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

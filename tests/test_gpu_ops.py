@@ -842,6 +842,29 @@ def test_lstm_skip_matches_torch_lstm(B, T, dtype, persist, monkeypatch):
     assert not ops.lstm_persist_error()
 
 
+def test_lstm_persist_error_flag_is_sticky_across_launches():
+    """the persistent LSTM's error word must survive later launches (a launch clears only its own abort word and
+    counters), so a timeout early in an epoch is still visible when the flag is read at its end.  The flag is raised by hand
+    here (a real timeout needs a lost residency); a forward and a backward launch later it still stands, those launches ran
+    normally (the per-launch abort word is separate), and reading it with clear=True re-arms it."""
+    torch.manual_seed(11)
+    H, B, T = 512, 5, 6
+    lstm = torch.nn.LSTM(H, H, 2)
+    w = ops.prepare_lstm_weights(lstm.to(DEV), torch.bfloat16)
+    x = (0.5 * torch.randn(B, T, H, device=DEV)).bfloat16().requires_grad_(True)
+    y0 = ops.LstmSkip.apply(x, w)
+    g0, = torch.autograd.grad(y0, x, torch.ones_like(y0))
+    assert not ops.lstm_persist_error()
+    ws = ops._lstm_workspace(torch.device(DEV))
+    ws[:4].view(torch.int32).fill_(1)  # what lp_wait leaves behind after a timeout
+    y1 = ops.LstmSkip.apply(x, w)
+    g1, = torch.autograd.grad(y1, x, torch.ones_like(y1))
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)   # the raised sticky word does not disturb later launches
+    assert ops.lstm_persist_error(clear=False)           # ... and they did not erase it
+    assert ops.lstm_persist_error()                      # report and clear
+    assert not ops.lstm_persist_error()
+
+
 def test_lds_window_kernel_matches_gathered_and_direct_kernels():
     """conv_win_kernel (input rows of a tile staged once in LDS, taps read from the window) on the two problem forms it takes:
     D blocks.1 forward (Cin 32, stride 4, k 41, zero padding at both ends, ragged last tile, fewer than 64 output channels too)

@@ -50,15 +50,30 @@ def test_sink_equals_plain_autograd_with_mode_seeking_and_r1():
         assert float(gb.abs().max()) > 0
         err = float((ga - gb).abs().max() / gb.abs().max())
         assert err <= 1e-5, (name, err)
-    # ... and so do the parameters after the step, up to what AdamW's first step (lr * g / (|g| + eps)) makes of that noise
-    # AdamW's first step is lr * g / (|g| + 1e-8): where an entry's gradient is itself of the size of the summation noise (a few
-    # 1e-9 here) the two paths may step in different directions -- by at most 2 lr, and that is all that can be asked of those
-    # entries (this bound, applied to every entry at 1e-4 of max|p|, is the likely cause of two failures in some twenty-five full-suite runs, never reproduced alone); entries
-    # whose gradient stands clear of the noise must agree
+    # ... and so do the parameters after the step, up to what AdamW's first step makes of that noise.  The first step is
+    # lr * g / (|g| + 1e-8), i.e. +-lr for every entry whose gradient is far above 1e-8, whatever its size: two paths whose
+    # gradients differ by summation noise land 2 lr apart exactly where the noise decides the SIGN (an entry whose true gradient
+    # is ~0, a few 1e-9 here) or where |g| is of the order of eps.  That is the only way the two paths can differ, and the test
+    # states it as such (the earlier form bounded EVERY entry at 1e-4 of max|p| and failed twice in some
+    # twenty-five full-suite runs): every entry that differs by more than 1e-4 of max|p| must be one whose gradient is
+    # noise-sized in both paths, and the message names the offenders with their gradients if one is not.
     for pa, pb, ga, gb, name in ((a[0], b[0], a[5], b[5], "G"), (a[1], b[1], a[6], b[6], "D")):
         diff = (pa - pb).abs()
-        assert float(diff.max()) <= 2.1e-3, (name, float(diff.max()))
-        clear = gb.abs() >= 1e-3 * gb.abs().max()
+        assert float(diff.max()) <= 2.1e-3, (name, float(diff.max()))  # 2 lr: the most a first step can disagree by
+        gmax = float(gb.abs().max())
+        noise = max(1e-5 * gmax, 1e-6)  # the gradient-agreement bound above / the eps regime of the update
+        big = diff > 1e-4 * float(pb.abs().max())
+        nbig = int(big.sum())
+        if nbig:
+            idx = big.nonzero().flatten()
+            gmag = torch.maximum(ga[idx].abs(), gb[idx].abs())
+            worst = idx[gmag.argmax()]
+            report = (f"{name}: {nbig} entries differ by more than 1e-4 max|p|; largest gradient among them at flat index "
+                      f"{int(worst)}: g_sink {float(ga[worst]):.3e}, g_plain {float(gb[worst]):.3e}, p_sink {float(pa[worst]):.6e}, "
+                      f"p_plain {float(pb[worst]):.6e}, max|g| {gmax:.3e}")
+            print(report)
+            assert float(gmag.max()) <= noise, report
+        clear = gb.abs() >= 1e-3 * gmax
         assert int(clear.sum()) > 0.2 * clear.numel()
         err = float(diff[clear].max() / pb.abs().max())
         assert err <= 1e-4, (name, err)

@@ -164,8 +164,8 @@ def _check(golden, prefix, out, G, D, rel):
             # an element with a near-zero gradient lands +-lr apart between two fp32 implementations), so they get 1e-3
             tol = max(1e-2, rel) if k == "g_grad_norm" else (max(1e-3, rel) if k == "d_grad_norm" and "/it1" not in prefix and prefix.startswith("seq") else rel)
             # the chained sequence amplifies last-bit differences: recompiling the fp32 LSTM step kernels with a different
-            # store order (outputs equal to 1 ulp, 2.4e-7: scratch/lstm_probe.py) moved it3 / it4 from 0.39 % / 0.43 % to
-            # 0.63 % / 1.04 % off the golden norm (scratch/seq_probe.py; run-to-run spread 0.02 %), so from the third
+            # store order (outputs equal to 1 ulp, 2.4e-7: tools/lstm_probe.py) moved it3 / it4 from 0.39 % / 0.43 % to
+            # 0.63 % / 1.04 % off the golden norm (tools/seq_probe.py; run-to-run spread 0.02 %), so from the third
             # iteration on the generator's norm is held to 2 %
             if k == "g_grad_norm" and prefix.startswith("seq") and prefix[-1] in "34":
                 tol = 2e-2

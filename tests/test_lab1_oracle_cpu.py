@@ -83,3 +83,33 @@ def test_logmel_against_torch_stft_and_filterbank_properties():
     loud = wav.clone(); loud[1] *= 1e5  # +100 dB: item 0 falls entirely under the shared floor
     g2 = LO.wave_to_logmel(loud.numpy(), 22050, 22050, 256)
     assert g2[:, :, :t].min() >= g2.max() - 80.0 - 1e-9 and g2[0, :, :t].min() == pytest.approx(g2.max() - 80.0, abs=1e-9)
+
+
+def test_adapter_gradient_matches_oracle_finite_differences_through_the_top_db_floor():
+    """gan_amd.lab1_adapter's autograd gradient against central differences of the float64 oracle, on a batch where one item lies
+    entirely under the shared top_db floor: torchaudio's amplitude_to_DB keeps the graph through `amax() - top_db`, so the
+    clamped bins' upstream gradient flows to the loudest bin of the batch (a detached floor - the round-2 code - drops it and
+    fails this check; the forward values are the same either way)."""
+    from gan_amd.lab1_adapter import Lab1WaveAdapter
+    torch.manual_seed(3)
+    wav = 0.05 * torch.randn(2, 1, 6000, dtype=torch.float64)
+    wav[0] *= 1e-5                                   # -100 dB: item 0 sits on the floor everywhere
+    w = torch.randn(2, 96, 64, dtype=torch.float64)  # upstream gradient
+    v = torch.randn_like(wav)
+    v[0] *= 1e-5
+    ad = Lab1WaveAdapter(24000, 22050, 64, torch.device("cpu"))
+    x = wav.float().requires_grad_(True)
+    out = ad(x)
+    assert out.shape == (2, 96, 64)
+    np.testing.assert_allclose(out.detach().numpy(), LO.wave_to_logmel(wav.numpy(), 24000, 22050, 64), atol=2e-3)
+    on_floor = out.detach()[0] <= out.detach().max() - 80.0 + 1e-4
+    assert int(on_floor.sum()) > 0.25 * on_floor.numel()  # (the frames past the signal's end are the -80 pad, not the floor)
+    g, = torch.autograd.grad((out.double() * w).sum(), x)
+    got = float((g.double() * v).sum())
+    eps = 1e-6
+    f = lambda t: float((torch.from_numpy(LO.wave_to_logmel(t.numpy(), 24000, 22050, 64)) * w).sum())
+    want = (f(wav + eps * v) - f(wav - eps * v)) / (2 * eps)
+    # the floor path alone: what a detached floor would lose
+    floor_part = float(w[out.detach().double() <= float(out.detach().max()) - 80.0 + 1e-6].sum())
+    assert abs(floor_part) > 1.0
+    assert got == pytest.approx(want, rel=2e-3, abs=1e-3 * abs(want) + 1e-6), (got, want)

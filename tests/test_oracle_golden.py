@@ -169,6 +169,25 @@ def test_iteration_sequence_period2_r1(golden):
         _check_iteration(golden, f"seq/it{it}", out, g_sd, d_sd, rel=2e-4 if it < 4 else 2e-3, check_grads=it < 4)
 
 
+def test_iteration_full_shape_gradients(fullgrad_golden):
+    """B=2, T=375 (S=120000): the oracle's D-step and G-step gradients, clip norms, losses and post-AdamW parameters against
+    what the reference produced at the full codec shape (tests/golden/make_golden_fullgrad.py; MR-STFT weight 0)."""
+    gold = fullgrad_golden
+    g_sd, d_sd, dec_sd = O.fresh_state()
+    cfg = O.StepCfg(weights=O.Weights(content=0.0, style=0.0, mrstft=0.0))
+    out = O.iteration(g_sd, d_sd, dec_sd, O.AdamWState(), O.AdamWState(), make_inputs(2, 375, "fullgrad"), 1, cfg, record=True)
+    assert_summary_close(out["q_hat"], gold["fullgrad/q_hat"], RTOL, "q_hat")
+    assert_summary_close(out["x_hat"], gold["fullgrad/x_hat"], RTOL, "x_hat")
+    _check_iteration(gold, "fullgrad", out, g_sd, d_sd)
+    for kind, sd in (("d", d_sd), ("g", g_sd)):
+        flat = torch.cat([out[f"{kind}_grads"][k].reshape(-1) for k in sd])  # state-dict order = named_parameters order
+        sub = flat[::int(gold[f"fullgrad/stride_{kind}"])].double().numpy()
+        want = gold[f"fullgrad/{kind}_grad_sub"].astype(np.float64)
+        assert sub.shape == want.shape
+        rel = np.linalg.norm(sub - want) / np.linalg.norm(want)
+        assert rel < 2e-3, (kind, rel)
+
+
 def test_bank_helpers(golden):
     zs = proc_input((10, 128), "bank.zs", 0).numpy()
     gi = np.array([0, 1, 2, 3, 0, 1, 2, 0, 1, 0], dtype=np.int64)

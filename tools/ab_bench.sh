@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/ab_bench.sh VAR A B [rounds]   interleaved bench runs with VAR=A and VAR=B (same box, fresh process each)
+# usage: tools/ab_bench.sh VAR A B [rounds]   interleaved bench runs with VAR=A and VAR=B (same box, fresh process each)
 var=$1; a=$2; b=$3; n=${4:-3}
 for i in $(seq $n); do
   for v in $a $b; do

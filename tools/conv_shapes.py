@@ -1,4 +1,4 @@
-"""A few D-layer conv launches, five of each, for a per-shape rocprofv3 --pmc FETCH_SIZE pass (scratch/pmc_shapes.sh)."""
+"""A few D-layer conv launches, five of each, for a per-shape rocprofv3 --pmc FETCH_SIZE pass (tools/pmc_shapes.sh)."""
 import sys, torch
 sys.path.insert(0, ".")
 from gan_amd import _lib as L, ops

@@ -20,7 +20,7 @@ for dtype in (torch.float32, torch.bfloat16):
             out[f"{dtype}_{persist}_{B}_{T}"] = (y.detach().float().cpu(), gx.float().cpu())
 torch.save(out, f"gpurun_out/lstm_probe_{tag}.pt")
 if len(sys.argv) > 2:
-    ref = torch.load(f"scratch/lstm_probe_{sys.argv[2]}.pt")
+    ref = torch.load(f"tools/lstm_probe_{sys.argv[2]}.pt")
     for k in out:
         print(k, "y equal", torch.equal(out[k][0], ref[k][0]), "gx equal", torch.equal(out[k][1], ref[k][1]),
               "max dgx", (out[k][1] - ref[k][1]).abs().max().item())

@@ -1,6 +1,6 @@
 """Summarise one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE) into per-kernel MFMA utilisation.
 
-usage: python scratch/pmc_mfma.py <counter_collection.csv> <out.json>
+usage: python tools/pmc_mfma.py <counter_collection.csv> <out.json>
 
 mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 256 CUs x 4 SIMDs), kernel cycles = GRBM_GUI_ACTIVE / 8
 (rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts cycles, 32 per

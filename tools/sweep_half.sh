@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/sweep_half.sh  (GPU box) - correctness with the 64x128 tiles forced wide, then bench per threshold
+# usage: tools/sweep_half.sh  (GPU box) - correctness with the 64x128 tiles forced wide, then bench per threshold
 set -e
 GA_GEMM_HALF_MAX=100000 timeout -k 10 300 python -u -m pytest tests/test_gpu_ops.py tests/test_gpu_step.py -x -q --timeout 120 --timeout-method thread > gpurun_out/half_tests.log 2>&1
 for h in 0 100 180 300 600; do
