@@ -29,6 +29,12 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void glds16(uintptr_t src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
+// 16 bytes per lane, buffer resource + 32-bit vector offset + scalar offset -> LDS (wave-uniform base + lane * 16).  (A plain
+// function on purpose: called from a value-dependent context -- `if constexpr` inside a kernel template -- the builtin fails
+// the HOST pass's target-feature check at instantiation time and the whole instantiation silently loses its host stub.)
+__device__ __forceinline__ void bglds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
 // branch-free "ok ? a : z" on addresses (a ternary on pointers makes hipcc branch around two separate loads)
 __device__ __forceinline__ uintptr_t sel_addr(bool ok, uintptr_t a, uintptr_t z) {
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
@@ -54,7 +60,12 @@ __device__ __forceinline__ void divmod_small(int n, int d, float rcp, int& q, in
 #endif
 static constexpr bool SETPRIO = GA_GEMM_SETPRIO;
 
-template <int MI, int WM, int WN, int NBUF>
+// BUF: operand staging by direct-to-LDS BUFFER loads (zero padding, whole K-steps, tensors under 2 GiB): the per-lane part of an
+// address is a constant 32-bit byte offset, the K position a scalar offset, and padding is the hardware's range check (a lane
+// whose input row lies outside its batch item gets an offset beyond the buffer and receives zeros) -- per load: add + compare +
+// select for the gathered operand, nothing for the weights, where the flat-address form selects a 64-bit address against a zero
+// page with ~10 vector and ~12 scalar instructions per load.
+template <int MI, int WM, int WN, int NBUF, bool BUF = false>
 __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && MI == 2) ? GA_GEMM_NBUF1_WAVES : 1)) void conv_gemm_kernel(ConvParams p, int nN, int total, int Ktot, int nsteps, int Ntot, int mgroup_flags) {
     constexpr int WMR = MI * 32;               // rows (m) per wave
     constexpr int BM = WM * WMR, BN = WN * 64;
@@ -136,6 +147,21 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
         bR[i] = (p.t0 + tl) * S + off0;
         rb[i] = xitem[i] + (uintptr_t)((long)bR[i] * Cin * 2);
     }
+    // BUF: constant per-lane byte offsets (row start + this lane's 16-byte piece); the K position below then leaves `piece` out
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned avo[NA], bvo[NB];
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, BUF ? (int)((long)p.M * Ktot * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, BUF ? (int)((long)p.B * p.Lin * Cin * 2) : 0, 0x00020000);
+    if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) avo[i] = abase[i] ? (unsigned)(abase[i] - (uintptr_t)w) + piece * 16u : OOB;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            bvo[i] = (unsigned)(rb[i] - (uintptr_t)p.x) + piece * 16u;
+            if (!xitem[i]) bR[i] = 0x3fffffff;  // rows past the end fail every bounds test
+        }
+    }
+    const int pk = BUF ? 0 : piece * 8;  // (the flat form carries the lane's piece inside the K position)
     const int tapB = p.tap_step * Cin * 2;  // bytes between taps in a row window
     int st_dj, st_dc;
     divmod_small(GBK, Cin, __builtin_amdgcn_rcpf((float)Cin), st_dj, st_dc);
@@ -163,24 +189,44 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
             }
             st_j = st_phi + t * TS;
         }
-        st_c = cc0 * GBK + piece * 8;
+        st_c = cc0 * GBK + pk;
         st_k = st_j * Cin + st_c;
         st_dR = st_j * p.tap_step;
         st_kk = st_j * tapB + st_c * 2;
     } else {
-        st_k = ks_begin * GBK + piece * 8;
+        st_k = ks_begin * GBK + pk;
         int j0;
         divmod_small(st_k, Cin, __builtin_amdgcn_rcpf((float)Cin), j0, st_c);
         st_dR = j0 * p.tap_step;
         st_kk = j0 * tapB + st_c * 2;
     }
     const bool reflect = p.pad_mode == 1;
+    if constexpr (BUF) {  // the K position is wave-uniform: keep it in scalar registers
+        st_k = __builtin_amdgcn_readfirstlane(st_k);
+        st_c = __builtin_amdgcn_readfirstlane(st_c);
+        st_dR = __builtin_amdgcn_readfirstlane(st_dR);
+        st_kk = __builtin_amdgcn_readfirstlane(st_kk);
+        st_j = __builtin_amdgcn_readfirstlane(st_j);
+        st_phi = __builtin_amdgcn_readfirstlane(st_phi);
+    }
 
     // issues the direct-to-LDS loads of the NEXT stage in sequence (stages are issued in K order, each exactly once)
     auto issue = [&](int buf) {
         const bool kin = st_k < Ktot;
         char* const ab = Al + buf * (BM * 128) + wid * 1024;
         char* const bb = Bl + buf * (BN * 128) + wid * 1024;
+        if constexpr (BUF) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                bglds16(rsA, ab + i * (NT * 16), avo[i], st_k * 2);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const bool ok = (unsigned)(bR[i] + st_dR) < (unsigned)p.Lin;
+                // (the tap offset is added on the vector side, in wrapping 32-bit arithmetic: a window that starts in the left
+                // padding has a "negative" bvo, and only the sum is a valid offset)
+                bglds16(rsB, bb + i * (NT * 16), ok ? bvo[i] + (unsigned)st_kk : OOB, 0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             glds16(sel_addr(kin && abase[i], abase[i] + (uintptr_t)(st_k * 2), zero), ab + i * (NT * 16));
@@ -200,6 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NBUF == 1 && WM == 2 && WN == 2 && 
                 const bool ok = kin && xitem[i] && R < p.Lin;
                 glds16(sel_addr(ok, xitem[i] + (uintptr_t)(((long)R * Cin + st_c) * 2), zero), bb + i * (NT * 16));
             }
+        }
         }
         if (tapfast && TS > 1) {
             st_j += TS;
@@ -611,13 +658,25 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     size_t lds = NBUF * (BM + BN) * 128;
     const size_t epi = WM * WN * 32 * (MI * 32 + 4) * sizeof(float);
     if (lds < epi) lds = epi;
-    auto kern = conv_gemm_kernel<MI, WM, WN, NBUF>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GA_ERR_LAUNCH;
-    }
+    // buffer-load staging where it applies (zero padding, whole K-steps, 32-bit byte offsets); GA_GEMM_BUF=0 keeps the flat form
+    const char* eb = getenv("GA_GEMM_BUF");
+    const bool buf = !(eb && eb[0] == '0') && p.pad_mode == 0 && Ktot % GBK == 0 &&
+                     (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64 && (long)p.M * Ktot * 2 < (1L << 31) - 64;
     const int grid = (int)((total + 7) / 8 * 8);
-    kern<<<grid, WM * WN * 64, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup());
+    const int flags = ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup();
+    // (two explicit launches: taking the address of the BUF = true instantiation into a function pointer fails to compile
+    // for the host with this hipcc, a direct launch or a cast to const void* does not)
+    if (buf) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_gemm_kernel<MI, WM, WN, NBUF, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GA_ERR_LAUNCH;
+        conv_gemm_kernel<MI, WM, WN, NBUF, true><<<grid, WM * WN * 64, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, flags);
+    } else {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_gemm_kernel<MI, WM, WN, NBUF, false>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GA_ERR_LAUNCH;
+        conv_gemm_kernel<MI, WM, WN, NBUF, false><<<grid, WM * WN * 64, lds, s>>>(p, nN, (int)total, Ktot, nsteps, Ntot, flags);
+    }
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for f in "$@"; do
   name=$(basename "$f" .py)
-  timeout -k 10 420 python -u -m pytest "$f" -m gpu -v --timeout 180 --timeout-method thread -x --tb=short > "gpurun_out/$name.log" 2>&1
+  timeout -k 10 420 python -u -m pytest "$f" -m gpu -v --timeout 180 --timeout-method thread -x --tb=short -rP > "gpurun_out/$name.log" 2>&1
   rc=$?
   echo "$f -> exit $rc"; tail -n 25 "gpurun_out/$name.log"
   if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping: abnormal exit $rc"; exit $rc; fi
