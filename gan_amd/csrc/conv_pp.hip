@@ -496,7 +496,7 @@ int ga_conv_pp_wanted(const ConvParams& p) {
         // workgroup per CU (same-process A/B at B = 128, tools/pp_ab.py: D blocks.4 forward 1300 vs 1077 TFLOP/s, blocks.3 forward
         // 1094-1205 vs 1038-1090, blocks.4 data gradient 1136 vs 1046; shorter K and half-empty grids stay on the 128x128 kernel)
         mode = pp_env("GA_GEMM_PP", 1);
-        min_steps = pp_env("GA_GEMM_PP_MIN_STEPS", 80);
+        min_steps = pp_env("GA_GEMM_PP_MIN_STEPS", 128);  // (in the step, with its colder caches and fuller epilogues, only K >= 8192 wins: D blocks.4 forward)
         min_blocks = pp_env("GA_GEMM_PP_MIN_BLOCKS", 192);
     }
     if (!mode || !ga_conv_pp_supported(p)) return 0;

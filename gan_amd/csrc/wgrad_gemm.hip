@@ -31,6 +31,10 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void wg_glds16(uintptr_t src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
+// 16 bytes per lane: buffer resource + 32-bit byte offset -> LDS (a plain function: see bglds16 in conv_gemm.hip)
+__device__ __forceinline__ void wg_bglds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_base, 16, voff, 0, 0, 0);
+}
 __device__ __forceinline__ uintptr_t wg_sel(bool ok, uintptr_t a, uintptr_t z) {
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
 }
@@ -56,7 +60,12 @@ static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0
 // NBUF = 1: one buffer, 32 KiB, 128 registers: four workgroups per CU hide each other's load round trips (the form that won for
 //           the forward kernel on grids several workgroups per CU deep).
 // NB = number of 128-column gathered-X tiles per workgroup: 1 (128 x 128 block tile) or 2 (64 x 256, M <= 64 only)
-template <int NBUF, int NB>
+// BUF: both operands staged by direct-to-LDS BUFFER loads (tensors under 2 GiB): every row this lane stages carries a running
+// 32-bit byte offset into g and into x that advances by a constant per reduction step (and by another constant when the row
+// wraps into the next batch item), so a load needs no 64-bit address arithmetic; rows past the end, columns past M / K and
+// taps outside the item get an offset beyond the buffer and the hardware's range check returns zeros for them.  The bias
+// column's constant-one piece is written to its LDS slot once, up front: the lane that owns the slot never loads into it.
+template <int NBUF, int NB, bool BUF = false>
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total, int base, int total, int xcd_order) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     // work item = (output tile bx, reduction slice by), tiles fastest.  Workgroups are dealt to the 8 XCDs round-robin, so in
@@ -117,9 +126,67 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     const bf16_t* __restrict__ g = (const bf16_t*)p.g;
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
 
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, BUF ? (int)((long)p.B * p.LgTot * p.M * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, BUF ? (int)((long)p.B * p.Lin * Cin * 2) : 0, 0x00020000);
+    unsigned grow[4], xrow[4];  // byte offsets of (row's batch item, row's step t, column 0) in g / (item, input row t*S, channel 0) in x
+    unsigned xcol[NB];          // + this lane's (tap, channel) inside the row window
+    if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            grow[i] = (unsigned)((rb[i] * p.LgTot + rt[i]) * p.M) * 2u;
+            xrow[i] = (unsigned)((rb[i] * p.Lin + rt[i] * S) * Cin) * 2u;
+        }
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) xcol[sb] = (unsigned)(bdR[sb] * Cin + bc[sb]) * 2u;  // (wrapping: bdR may be negative)
+        // the bias column: its piece (bf16 1.0, seven zeros) goes into this lane's slot of every row instruction and buffer, once
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb)
+            if (b_one[sb]) {
+                for (int buf = 0; buf < NBUF; ++buf)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *(uint4*)(Bl + buf * NB * WGG_TILE + wid * 1024 + sb * WGG_TILE + i * 4096 + lane * 16) = make_uint4(0x00003F80u, 0u, 0u, 0u);
+            }
+    }
+    const unsigned g_step = (unsigned)(WGG_RK * p.M) * 2u, g_wrap = (unsigned)((p.LgTot - p.Lout) * p.M) * 2u;
+    const unsigned x_step = (unsigned)(WGG_RK * S * Cin) * 2u, x_wrap = (unsigned)((p.Lin - p.Lout * S) * Cin) * 2u;
+
     auto issue = [&](int buf) {
         char* const ab = Al + buf * ATILE + wid * 1024;
         char* const bb = Bl + buf * NB * WGG_TILE + wid * 1024;
+        if constexpr (BUF) {
+            if (NB == 2) {
+                const bool up = lpiece >= 8;
+                const unsigned am2b = (unsigned)((lpiece & 7) * 8) * 2u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int b_ = up ? rb[i + 2] : rb[i];
+                    const unsigned go = up ? grow[i + 2] : grow[i];
+                    wg_bglds16(rsG, ab + i * 4096, (b_ < p.B && (lpiece & 7) * 8 < p.M) ? go + am2b : OOB);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool n_ok = rb[i] < p.B;
+                if (NB == 1) wg_bglds16(rsG, ab + i * 4096, (n_ok && a_ok) ? grow[i] + (unsigned)am * 2u : OOB);
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) {
+                    const bool ok = n_ok && b_ok[sb] && (unsigned)(rt[i] * S + bdR[sb]) < (unsigned)p.Lin;
+                    if (!b_one[sb]) wg_bglds16(rsX, bb + sb * WGG_TILE + i * 4096, ok ? xrow[i] + xcol[sb] : OOB);
+                }
+                rt[i] += WGG_RK;
+                grow[i] += g_step;
+                xrow[i] += x_step;
+                while (rt[i] >= p.Lout) {
+                    rt[i] -= p.Lout;
+                    ++rb[i];
+                    grow[i] += g_wrap;
+                    xrow[i] += x_wrap;
+                }
+            }
+            return;
+        }
         if (NB == 2) {  // LDS row rho = i*16 + wid*4 + prow: pieces 0-7 = columns of reduction row rho, pieces 8-15 = of row rho + 32
             const bool up = lpiece >= 8;
             const int am2 = (lpiece & 7) * 8;
@@ -342,20 +409,26 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
     const long total = base * splits;
     if (total > (1L << 30)) return GA_ERR_ARG;
     const unsigned grid = (unsigned)((total + 7) / 8 * 8);
+    // buffer-load staging where the 32-bit byte offsets reach (GA_WGRAD_BUF=0: the flat-address form)
+    const char* eb = getenv("GA_WGRAD_BUF");
+    const bool buf = !(eb && eb[0] == '0') && (long)p.B * p.LgTot * p.M * 2 < (1L << 31) - 64 && (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64;
+#define WGG_LAUNCH(NBUF_, NB_, LDS_, XCD_)                                                                                          \
+    do {                                                                                                                            \
+        if (buf) wgrad_gemm_kernel<NBUF_, NB_, true><<<grid, 256, LDS_, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps, (int)base, (int)total, XCD_);  \
+        else wgrad_gemm_kernel<NBUF_, NB_, false><<<grid, 256, LDS_, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps, (int)base, (int)total, XCD_);    \
+    } while (0)
     if (wgg_wide64(p)) {
-        wgrad_gemm_kernel<1, 2><<<grid, 256, WGG_TILE / 2 + 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps, (int)base, (int)total, xcd_wide);
+        WGG_LAUNCH(1, 2, WGG_TILE / 2 + 2 * WGG_TILE, xcd_wide);
     } else if (nbuf == 1) {
-        wgrad_gemm_kernel<1, 1><<<grid, 256, 2 * WGG_TILE, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps, (int)base, (int)total, xcd_all);
+        WGG_LAUNCH(1, 1, 2 * WGG_TILE, xcd_all);
     } else {
         const size_t lds = 4 * WGG_TILE;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)wgrad_gemm_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return GA_ERR_LAUNCH;
-            attr_set = true;
-        }
-        wgrad_gemm_kernel<2, 1><<<grid, 256, lds, s>>>(p, ktiles, Ktot, (int)Ntot, sps, (int)nsteps, (int)base, (int)total, xcd_all);
+        if (hipFuncSetAttribute(buf ? (const void*)wgrad_gemm_kernel<2, 1, true> : (const void*)wgrad_gemm_kernel<2, 1, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GA_ERR_LAUNCH;
+        WGG_LAUNCH(2, 1, lds, xcd_all);
     }
+#undef WGG_LAUNCH
     GA_CHECK_LAUNCH();
     if (p.ws) {
         const long n4 = (long)p.M * Ktot / 4;
