@@ -31,6 +31,10 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void cw_glds16(uintptr_t src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
+// 16 bytes per lane: buffer resource + 32-bit vector byte offset + scalar byte offset -> LDS (plain function: see bglds16, conv_gemm.hip)
+__device__ __forceinline__ void cw_bglds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ uintptr_t cw_sel(bool ok, uintptr_t a, uintptr_t z) {
     return z ^ ((z ^ a) & (uintptr_t)(-(long long)ok));
 }
@@ -38,7 +42,7 @@ __device__ __forceinline__ uintptr_t cw_sel(bool ok, uintptr_t a, uintptr_t z) {
 #define CW_BN 128
 
 template <int CIN, int S, int WM, int WN, int RING>
-__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void conv_win_kernel(ConvParams p, int tiles_per_item, int total, int Ktot, int nsteps) {
+__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void conv_win_kernel(ConvParams p, int tiles_per_item, int total, int Ktot, int nsteps, int mode_flags) {
     constexpr int MI = 2;                        // 32-row MFMA tiles per wave along m
     constexpr int NI = CW_BN / (WN * 32);        // along n
     constexpr int BM = WM * MI * 32;
@@ -96,10 +100,22 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void conv_win_kernel(ConvPa
         const int m = mbase + i * 32 + (tid >> 3);
         abase[i] = m < p.M ? (uintptr_t)(w + (size_t)m * Ktot + apiece * 8) : 0;
     }
+    // weights by buffer loads: constant per-lane byte offset + the K-step as the scalar offset; rows past M and, in the last
+    // K-step of a K that is no multiple of 64, pieces past Ktot get an offset beyond the buffer (the range check returns zeros)
+    const bool wbuf = (mode_flags & 1) && (long)p.M * Ktot * 2 < (1L << 31) - 64;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbuf ? (int)((long)p.M * Ktot * 2) : 0, 0x00020000);
+    unsigned avo[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) avo[i] = abase[i] ? (unsigned)(abase[i] - (uintptr_t)w) : 0x80000000u;
     auto issue_A = [&](int step, int buf) {
         const int k = step * 64 + apiece * 8;
         const bool kin = k < Ktot;
         char* const dst = Al + buf * ABYTES + wid * 1024;
+        if (wbuf) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) cw_bglds16(rsA, dst + i * 4096, kin ? avo[i] : 0x80000000u, step * 128);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             cw_glds16(cw_sel(kin && abase[i], abase[i] + (uintptr_t)step * 128, zero), dst + i * 4096);
@@ -255,11 +271,8 @@ int ga_conv_win_supported(const ConvParams& p) {
 }
 
 int ga_conv_win_wanted(const ConvParams& p) {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("GA_CONV_WIN");
-        mode = e ? atoi(e) : 2;
-    }
+    const char* e = getenv("GA_CONV_WIN");  // (read per call: in-process A/B)
+    const int mode = e ? atoi(e) : 2;
     if (!mode) return 0;
     const int kind = ga_conv_win_supported(p);
     if (!kind) return 0;
@@ -291,7 +304,8 @@ static int launch_win(const ConvParams& p, hipStream_t s) {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GA_ERR_LAUNCH;
     const int grid = (int)((total + 7) / 8 * 8);
-    kern<<<grid, 256, lds, s>>>(p, tpi, (int)total, Ktot, nsteps);
+    const char* eb = getenv("GA_CONV_WIN_BUF");  // "0": flat-address weight loads (A/B aid)
+    kern<<<grid, 256, lds, s>>>(p, tpi, (int)total, Ktot, nsteps, (eb && eb[0] == '0') ? 0 : 1);
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
