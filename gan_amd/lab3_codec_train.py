@@ -14,6 +14,8 @@ gan_amd.lab1_adapter.Lab1WaveAdapter (the torchaudio-free restatement of `_Lab1W
 """
 from __future__ import annotations
 
+import os
+
 import warnings
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -251,6 +253,26 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
         dp.allreduce_flat(opt)
 
 
+# Frozen decodes on a side stream beside the generator pass and the decode of q_hat: 48.25 -> 47.6 ms per step at B = 64 (same-box
+# A/B).  Starting them a whole iteration ahead (while the previous D / G steps run) was measured too: 48.6 -> 48.2 only -- the step
+# is throughput-bound there, and the persistent LSTM's 96 KiB of LDS per CU halves the co-resident GEMM workgroups -- not kept.
+ASYNC_FROZEN_DECODE = os.environ.get("GA_ASYNC_FROZEN", "1") == "1"
+
+
+def _frozen_decode_stream(codec, device):
+    """The side stream of the frozen decodes, or None (off, not a GPU codec, or the codec's first iteration: its packed
+    weights and LSTM layouts are built lazily by the first decode, which therefore runs on the main stream alone)."""
+    if not ASYNC_FROZEN_DECODE or device.type != "cuda" or not hasattr(codec, "decode_embeddings_mixed"):
+        return None
+    st = getattr(codec, "_frozen_side_stream", None)
+    if st is None:
+        codec._frozen_side_stream = False  # (first call: warm-up on the main stream)
+        return None
+    if st is False:
+        st = codec._frozen_side_stream = torch.cuda.Stream(device=device)
+    return st
+
+
 def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLatentTranslator,
                           discriminator: MultiScaleWaveDiscriminator, codec, opt_g: FusedAdamW, opt_d: FusedAdamW,
                           q_src: torch.Tensor, zc_src: torch.Tensor, z_style_tgt: torch.Tensor, noise: torch.Tensor,
@@ -266,20 +288,35 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     With neither a judge nor a Lab1 encoder the content and style terms stay at zero (the north-star loss subset)."""
     device = q_src.device
     out: Dict[str, torch.Tensor] = {}
-    q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
-                      style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
     take_d_step = (global_step % max(1, int(stage_cfg.d_step_period))) == 0
     # The reference decodes q_src, q_real_tgt and q_real_tgt_g in three separate no-grad calls (:415,422,458).  The
     # decoder is frozen and acts on every batch item independently, so one batched call gives the same waveforms with a
     # third of the (launch-bound) LSTM steps.
     B0 = int(q_src.shape[0])
     frozen_list = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
-    if hasattr(codec, "decode_embeddings_mixed"):
-        x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, torch.cat(frozen_list, dim=0))
-    else:
-        x_hat = codec.decode_embeddings(q_hat)
-        with torch.no_grad():
+    side = _frozen_decode_stream(codec, device)
+    if side is not None:
+        # The frozen decodes depend on the batch alone, not on G: they start on a side stream BEFORE the generator pass and run
+        # beside it and beside the decode of q_hat (their LSTM is latency-bound, the generator's small convolutions are too, the
+        # decoder's tail is HBM-bound: the three fill each other's gaps).  The main stream joins right before D needs the waveforms.
+        main = torch.cuda.current_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
             frozen_out = codec.decode_embeddings(torch.cat(frozen_list, dim=0))
+        q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
+                          style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+        x_hat = codec.decode_embeddings(q_hat)
+        main.wait_stream(side)
+        frozen_out.record_stream(main)
+    else:
+        q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
+                          style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+        if hasattr(codec, "decode_embeddings_mixed"):
+            x_hat, frozen_out = codec.decode_embeddings_mixed(q_hat, torch.cat(frozen_list, dim=0))
+        else:
+            x_hat = codec.decode_embeddings(q_hat)
+            with torch.no_grad():
+                frozen_out = codec.decode_embeddings(torch.cat(frozen_list, dim=0))
     with torch.no_grad():
         x_src = frozen_out[:B0]
         x_real_d_all = frozen_out[B0:2 * B0] if take_d_step else None

@@ -174,6 +174,75 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     close(outs[L.IMPL_MFMA][1], outs[L.IMPL_DIRECT][1], 1e-2, f"{g} dgrad")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvGeom("conv", 64, 128, 41, 4, 20, 1), 2050, 2),    # D block 2 (phase-fast taps), windows that start in the left padding of item 0
+    (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 469, 3),    # D block 4: tiles span batch items, ragged last tile
+    (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 3),      # G dilated conv: padding 8 rows at both ends of every item
+    (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 37, 5),       # short rows: several items per tile
+    (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 3),     # Cin 32: two taps per K-step (K = 1312 is no multiple of 64: flat form both times)
+], ids=lambda c: f"{c[0].cin}-{c[0].cout}-k{c[0].k}s{c[0].stride}-L{c[1]}")
+def test_buffer_load_staging_is_bit_identical_to_flat_addresses(case, monkeypatch):
+    """Round 3: operands staged by buffer_load ... lds (constant per-lane offsets, zero padding by the hardware range check)
+    against the flat-address form with its zero-page select: same K order, same accumulation order, so forward, data gradient
+    and (to fp32 atomics order) weight gradient must agree bit for bit / to 1e-6 -- the range check must return zeros exactly
+    where the select read the zero page (rows before / after an item, rows past the last output row, channels past M)."""
+    g, Ln, B = case
+    torch.manual_seed(21)
+    x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+    w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+    bias = torch.randn(g.cout, device=DEV)
+    gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+    wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("GA_GEMM_BUF", v)
+        monkeypatch.setenv("GA_WGRAD_BUF", v)
+        monkeypatch.setenv("GA_CONV_WIN_BUF", v)
+        ops.set_conv_impl(L.IMPL_MFMA)
+        try:
+            yf = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU)
+            dx = ops.conv_dgrad(g, gy, wd, Ln)
+        finally:
+            ops.set_conv_impl(L.IMPL_AUTO)
+        dw = ops.conv_wgrad(g, gy, x, want_bias=True)  # (the bias gradient rides in the weight-gradient GEMM as a constant-one column)
+        outs[v] = (yf, dx, [t.float() for t in (dw if isinstance(dw, (tuple, list)) else [dw]) if t is not None])
+    assert torch.equal(outs["0"][0], outs["1"][0]), "forward"
+    assert torch.equal(outs["0"][1], outs["1"][1]), "data gradient"
+    for a, b in zip(outs["0"][2], outs["1"][2]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), "weight gradient"
+
+
+def test_ping_pong_kernel_is_bit_identical_to_the_gathered_kernel():
+    """conv_pp_kernel (256 x 256 tiles, eight waves, 16x16x32 MFMAs, buffer-load staging, phase-fast taps) on the shapes AUTO
+    gives it (D blocks.4 forward, K = 10496) and on a folded data gradient: same K order and per-output accumulation order
+    as conv_gemm_kernel, so the results agree to the last bit; both MFMA shapes of the kernel."""
+    torch.manual_seed(22)
+    g = ConvGeom("conv", 256, 512, 41, 4, 20, 1)
+    B, Ln = 3, 1875
+    x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+    w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+    bias = torch.randn(g.cout, device=DEV)
+    gy = torch.randn(B, g.out_len(Ln), g.cout, device=DEV).bfloat16()
+    wf, wd = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16), ops.pack_weight(g, w, g.dgrad_pack, torch.bfloat16)
+    outs = {}
+    import os
+    for name, impl, mf in (("gemm", L.IMPL_MFMA, None), ("pp16", L.IMPL_MFMA_PP, "16"), ("pp32", L.IMPL_MFMA_PP, "32")):
+        if mf is not None:
+            os.environ["GA_GEMM_PP_MFMA"] = mf
+        ops.set_conv_impl(impl)
+        try:
+            outs[name] = (ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU), ops.conv_dgrad(g, gy, wd, Ln))
+        finally:
+            ops.set_conv_impl(L.IMPL_AUTO)
+            os.environ.pop("GA_GEMM_PP_MFMA", None)
+    for name in ("pp16", "pp32"):
+        assert torch.equal(outs[name][0], outs["gemm"][0]), name + " forward"
+        assert torch.equal(outs[name][1], outs["gemm"][1]), name + " data gradient"
+    # and AUTO hands the full-size layer to it (K = 10496, a grid of about two workgroups per CU)
+    p = ops.fwd_params(g, 128, 30000)
+    assert L.lib().ga_conv_kernel_id(__import__("ctypes").byref(p), 1, L.IMPL_AUTO) == 11
+
+
 STREAM_CASES = [
     # thin layers (M <= 64, K = J*Cin <= 192): operands straight from global memory into MFMA fragments
     (ConvGeom("cconv", 64, 32, 3), 1201, 3),       # K = 192: 12 k-steps, no register double buffer
