@@ -660,7 +660,9 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     if (lds < epi) lds = epi;
     // buffer-load staging where it applies (zero padding, whole K-steps, 32-bit byte offsets); GA_GEMM_BUF=0 keeps the flat form
     const char* eb = getenv("GA_GEMM_BUF");
-    const bool buf = !(eb && eb[0] == '0') && p.pad_mode == 0 && Ktot % GBK == 0 &&
+    // (Cin a multiple of the K-step: a K-step then lies inside ONE tap for every lane, which is what makes the K position
+    // wave-uniform; with other channel counts the lanes of a K-step straddle taps and the flat form's per-lane state is needed)
+    const bool buf = !(eb && eb[0] == '0') && p.pad_mode == 0 && p.Cin % GBK == 0 &&
                      (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64 && (long)p.M * Ktot * 2 < (1L << 31) - 64;
     const int grid = (int)((total + 7) / 8 * 8);
     const int flags = ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup();

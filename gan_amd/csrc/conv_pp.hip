@@ -474,7 +474,7 @@ int ga_conv_gemm_supported(const ConvParams& p);
 // The ping-pong kernel takes what the gathered-GEMM kernel takes, single phase, with 32-bit element offsets.
 int ga_conv_pp_supported(const ConvParams& p) {
     if (!ga_conv_gemm_supported(p) || p.nphase != 1 || p.res_mode == GA_RES_ADD_THEN_ACT || p.y2) return 0;
-    if (p.pad_mode != 0 || ((long)p.J * p.Cin) % PBK != 0) return 0;  // zero padding by the buffer range check; whole K-steps only
+    if (p.pad_mode != 0 || p.Cin % PBK != 0) return 0;  // zero padding by the buffer range check; a K-step lies inside one tap (wave-uniform K position)
     if ((long)p.B * p.Lin * p.Cin * 2 >= (1L << 31) - 64 || (long)p.M * p.J * p.Cin * 2 >= (1L << 31) - 64) return 0;  // 32-bit byte offsets
     if ((long)p.B * p.Lin * p.Cin >= (1L << 31) - (1L << 24) || (long)p.M * p.J * p.Cin >= (1L << 31) - (1L << 24)) return 0;
     if ((long)(labs((long)p.off0) + (long)p.J * p.tap_step + 2) * p.Cin >= (1L << 24)) return 0;  // window offsets stay far from overflow

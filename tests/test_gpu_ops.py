@@ -179,7 +179,9 @@ def test_gathered_gemm_kernel_matches_window_and_direct(case):
     (ConvGeom("conv", 256, 512, 41, 4, 20, 1), 469, 3),    # D block 4: tiles span batch items, ragged last tile
     (ConvGeom("conv", 256, 256, 3, 1, 8, 8), 375, 3),      # G dilated conv: padding 8 rows at both ends of every item
     (ConvGeom("conv", 128, 256, 3, 1, 1, 1), 37, 5),       # short rows: several items per tile
-    (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 3),     # Cin 32: two taps per K-step (K = 1312 is no multiple of 64: flat form both times)
+    (ConvGeom("conv", 32, 64, 41, 4, 20, 1), 3001, 3),     # Cin 32: two taps per K-step (flat form both times: the K position is per-lane)
+    (ConvGeom("conv", 80, 64, 4, 1, 3, 1), 300, 2),        # K = 320 is a multiple of 64 but Cin is not: K-steps straddle taps (flat form)
+    (ConvGeom("conv", 192, 96, 5, 2, 2, 1), 401, 3),       # Cin = 3 x 64, tap-fast order, M = 96, stride 2
 ], ids=lambda c: f"{c[0].cin}-{c[0].cout}-k{c[0].k}s{c[0].stride}-L{c[1]}")
 def test_buffer_load_staging_is_bit_identical_to_flat_addresses(case, monkeypatch):
     """Round 3: operands staged by buffer_load ... lds (constant per-lane offsets, zero padding by the hardware range check)
@@ -230,10 +232,12 @@ def test_ping_pong_kernel_is_bit_identical_to_the_gathered_kernel():
         if mf is not None:
             os.environ["GA_GEMM_PP_MFMA"] = mf
         ops.set_conv_impl(impl)
+        ops.FORCE_KSPLIT = 1  # (the few tiles of this small batch would otherwise be split along K: another summation order)
         try:
             outs[name] = (ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU), ops.conv_dgrad(g, gy, wd, Ln))
         finally:
             ops.set_conv_impl(L.IMPL_AUTO)
+            ops.FORCE_KSPLIT = None
             os.environ.pop("GA_GEMM_PP_MFMA", None)
     for name in ("pp16", "pp32"):
         assert torch.equal(outs[name][0], outs["gemm"][0]), name + " forward"
