@@ -134,6 +134,8 @@ _SIGNATURES = {
     "ga_latent_loss_fwd": [_P, _P, _I, _I, _I, _I, _P, _P],
     "ga_latent_loss_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "ga_stft_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_power_spec_fwd": [_P, _Z, _I, _I, _P, _I, _P],
+    "ga_power_spec_bwd": [_P, _P, _Z, _I, _I, _I, _P, _P],
     "ga_stft_combine": [_P, _P, _I, _P, _P, _P, _P],
     "ga_stft_loss_fwd": [_P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_stft_loss_bwd": [_P, _P, _I, _Z, _I, _I, _P, _P, _P],

@@ -108,7 +108,60 @@ static inline int grid_for(size_t n, int cap = 2048) {
     return (int)g;
 }
 
+// power spectrum of a (re | im) spectrum row: p[f][k] = re^2 + im^2, k < nb; columns nb .. ldp-1 of p are written as zeros
+// (the mel filterbank GEMM behind it reads rows of ldp channels)
+__global__ __launch_bounds__(256) void power_spec_fwd_kernel(const float* __restrict__ spec, size_t frames, int nb, int ld, float* __restrict__ pw, int ldp) {
+    const size_t n = frames * (size_t)ldp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / ldp;
+        const int k = (int)(i - f * ldp);
+        float v = 0.f;
+        if (k < nb) {
+            const float re = spec[f * ld + k], im = spec[f * ld + nb + k];
+            v = re * re + im * im;
+        }
+        pw[i] = v;
+    }
+}
+// dspec = d/dspec of sum dp * p: (2 re dp | 2 im dp); the padding columns 2*nb .. ld-1 of dspec are zeroed
+__global__ __launch_bounds__(256) void power_spec_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ dp, size_t frames, int nb, int ld,
+                                                             int ldp, float* __restrict__ dspec) {
+    const size_t n = frames * (size_t)ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / ld;
+        const int c = (int)(i - f * ld);
+        float v = 0.f;
+        if (c < 2 * nb) {
+            const int k = c < nb ? c : c - nb;
+            v = 2.f * spec[i] * dp[f * ldp + k];
+        }
+        dspec[i] = v;
+    }
+}
+
 extern "C" {
+
+int ga_power_spec_fwd(const float* spec, size_t frames, int nb, int ldspec, float* power, int ldp, hipStream_t s) {
+    if (!spec || !power || nb < 1 || ldspec < 2 * nb || ldp < nb) return GA_ERR_ARG;
+    const size_t n = frames * (size_t)ldp;
+    if (!n) return GA_OK;
+    size_t grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    power_spec_fwd_kernel<<<(unsigned)grid, 256, 0, s>>>(spec, frames, nb, ldspec, power, ldp);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_power_spec_bwd(const float* spec, const float* dpower, size_t frames, int nb, int ldspec, int ldp, float* dspec, hipStream_t s) {
+    if (!spec || !dpower || !dspec || nb < 1 || ldspec < 2 * nb || ldp < nb) return GA_ERR_ARG;
+    const size_t n = frames * (size_t)ldspec;
+    if (!n) return GA_OK;
+    size_t grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    power_spec_bwd_kernel<<<(unsigned)grid, 256, 0, s>>>(spec, dpower, frames, nb, ldspec, ldp, dspec);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
 
 int ga_stft_pad(const void* x, void* xp, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows, int rep,
                 hipStream_t s) {

@@ -1444,6 +1444,83 @@ class StftSums(torch.autograd.Function):
         return dx.to(ctx.in_dtype), None, None, None, None, None, None
 
 
+class StftSpec(torch.autograd.Function):
+    """(re | im) spectrum [B, frames, M] (fp32) of x [B, S]: torch.stft(center=True, reflect pad, onesided, unnormalised) as the
+    reflect-pad kernel + the DFT-basis GEMM of StftSums, with the data gradient back to x.  Returns (spec, nb): columns
+    [0, nb) real parts, [nb, 2 nb) imaginary parts, the rest padding.  split: bf16 hi/lo MFMA GEMM (fp32-grade) / exact fp32."""
+
+    @staticmethod
+    def forward(ctx, x, n_fft: int, hop: int, win: int, split: bool):
+        L.require_cuda(x)
+        ctx.in_dtype = x.dtype
+        x = x.contiguous().float()
+        B, S = x.shape
+        lib = L.lib()
+        gdt = torch.bfloat16 if split else torch.float32
+        rep = 3 if split else 1
+        w_f, w_d, nb, M, J = _dft_basis(n_fft, hop, win, gdt, x.device, rep)
+        rows = (S + 2 * (n_fft // 2) + hop - 1) // hop
+        frames = 1 + S // hop
+        xp = torch.empty((B, rows, hop * rep), device=x.device, dtype=gdt)
+        L.check(lib.ga_stft_pad(x.data_ptr(), xp.data_ptr(), L.dt(x), L.dt(xp), B, S, n_fft, hop, rows, rep, L.stream()), "ga_stft_pad")
+        p = _new_params()
+        _fill(p, B=B, Lin=rows, Cin=hop * rep, M=M, Lout=frames, LoutTot=frames, J=J, off0=0, out_f32=1 if split else 0)
+        spec = torch.empty((B, frames, M), device=x.device, dtype=torch.float32)
+        _launch_conv(p, xp, w_f, spec, impl=_IMPL, alg_flops=2.0 * B * frames * n_fft * 2 * nb)
+        ctx.save_for_backward(w_d)
+        ctx.cfg = (B, S, n_fft, hop, rows, frames, nb, M, J, split)
+        return spec
+
+    @staticmethod
+    def backward(ctx, dspec):
+        w_d, = ctx.saved_tensors
+        B, S, n_fft, hop, rows, frames, nb, M, J, split = ctx.cfg
+        lib = L.lib()
+        dsx = dspec.contiguous().float()
+        if split:
+            dsx = dsx.to(torch.bfloat16)
+        p = _new_params()
+        _fill(p, B=B, Lin=frames, Cin=M, M=hop, Lout=rows, LoutTot=rows, J=J, off0=-(J - 1), out_f32=1 if split else 0)
+        dxp = torch.empty((B, rows, hop), device=dsx.device, dtype=torch.float32)
+        _launch_conv(p, dsx, w_d, dxp, impl=_IMPL, alg_flops=2.0 * B * frames * n_fft * 2 * nb)
+        dx = torch.empty((B, S), device=dsx.device, dtype=torch.float32)
+        L.check(lib.ga_stft_unpad_bwd(dxp.data_ptr(), dx.data_ptr(), L.DT_F32, L.DT_F32, B, S, n_fft, hop, rows, 0, L.stream()),
+                "ga_stft_unpad_bwd")
+        return dx.to(ctx.in_dtype), None, None, None, None
+
+
+def stft_bins(n_fft: int) -> Tuple[int, int]:
+    """(nb, M): bins and padded row width of StftSpec's output."""
+    nb = n_fft // 2 + 1
+    return nb, (2 * nb + 31) // 32 * 32
+
+
+class PowerSpec(torch.autograd.Function):
+    """power [rows, ldp] = re^2 + im^2 of a (re | im) spectrum [rows, ld] (columns >= nb zero): ga_power_spec_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, spec, nb: int, ldp: int):
+        L.require_cuda(spec)
+        spec = spec.contiguous()
+        assert spec.dtype == torch.float32
+        ld = int(spec.shape[-1])
+        frames = spec.numel() // ld
+        pw = torch.empty(spec.shape[:-1] + (ldp,), device=spec.device, dtype=torch.float32)
+        L.check(L.lib().ga_power_spec_fwd(spec.data_ptr(), frames, nb, ld, pw.data_ptr(), ldp, L.stream()), "ga_power_spec_fwd")
+        ctx.save_for_backward(spec)
+        ctx.cfg = (nb, ld, ldp, frames)
+        return pw
+
+    @staticmethod
+    def backward(ctx, dpw):
+        spec, = ctx.saved_tensors
+        nb, ld, ldp, frames = ctx.cfg
+        dpw = dpw.contiguous().float()
+        dspec = torch.empty_like(spec)
+        L.check(L.lib().ga_power_spec_bwd(spec.data_ptr(), dpw.data_ptr(), frames, nb, ld, ldp, dspec.data_ptr(), L.stream()), "ga_power_spec_bwd")
+        return dspec, None, None
+
+
 # ================================================================================================
 LSTM_PERSIST = True  # bf16, H = 512: one persistent launch per pass (lstm_persist.hip); tests switch it off to compare
 _LSTM_WS: dict = {}

@@ -406,6 +406,14 @@ int ga_stft_combine(const float* sums, const float* inv_count, int R, const floa
 int ga_stft_unpad_bwd(const void* dxp, void* dx, int dtype_in, int dtype_out, int B, int S, int n_fft, int hop, int rows,
                       int accumulate, ga_stream_t stream);
 
+/* Power spectrum either side of the mel filterbank GEMM of the Lab1 waveform -> log-mel adapter (lab3_codec_train.py:185-194,
+ * 208: torchaudio MelSpectrogram(power=2) = |STFT|^2 @ filterbank): power[f][k] = re^2 + im^2 from a (re | im) spectrum row of
+ * ldspec floats, written as rows of ldp floats (columns >= nb zero: the filterbank GEMM reads whole rows); and its gradient
+ * dspec = (2 re dpower | 2 im dpower), padding columns zero. */
+int ga_power_spec_fwd(const float* spec, size_t frames_total, int nb, int ldspec, float* power, int ldp, ga_stream_t stream);
+int ga_power_spec_bwd(const float* spec, const float* dpower, size_t frames_total, int nb, int ldspec, int ldp, float* dspec,
+                      ga_stream_t stream);
+
 /* torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step (lab3_codec_train.py:302-311,446-448,589-591) over flat
  * fp32 buffers: out[0] += sum g^2 (atomics); then p,m,v updated in one pass, clip coefficient
  * min(1, max_norm/(sqrt(sqnorm[0])*grad_scale + 1e-6)) folded in; grad_scale = 1/world_size under data parallel. */

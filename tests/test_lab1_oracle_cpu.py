@@ -90,16 +90,15 @@ def test_adapter_gradient_matches_oracle_finite_differences_through_the_top_db_f
     entirely under the shared top_db floor: torchaudio's amplitude_to_DB keeps the graph through `amax() - top_db`, so the
     clamped bins' upstream gradient flows to the loudest bin of the batch (a detached floor - the round-2 code - drops it and
     fails this check; the forward values are the same either way)."""
-    from gan_amd.lab1_adapter import Lab1WaveAdapter
+    from gan_amd.lab1_adapter import wave_to_logmel_torch
     torch.manual_seed(3)
     wav = 0.05 * torch.randn(2, 1, 6000, dtype=torch.float64)
     wav[0] *= 1e-5                                   # -100 dB: item 0 sits on the floor everywhere
     w = torch.randn(2, 96, 64, dtype=torch.float64)  # upstream gradient
     v = torch.randn_like(wav)
     v[0] *= 1e-5
-    ad = Lab1WaveAdapter(24000, 22050, 64, torch.device("cpu"))
     x = wav.float().requires_grad_(True)
-    out = ad(x)
+    out = wave_to_logmel_torch(x, 24000, 22050, 64)  # (the torch-op form of the adapter: the dB / top_db tail is shared with the HIP path)
     assert out.shape == (2, 96, 64)
     np.testing.assert_allclose(out.detach().numpy(), LO.wave_to_logmel(wav.numpy(), 24000, 22050, 64), atol=2e-3)
     on_floor = out.detach()[0] <= out.detach().max() - 80.0 + 1e-4
