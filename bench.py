@@ -30,6 +30,15 @@ KERNEL_NAMES = {0: "conv_direct_kernel", 1: "conv_fewout_kernel", 2: "conv_cin1_
                 6: "conv_cin1_vec_kernel", 7: "conv_gemm_kernel<2,1,4>", 8: "conv_gemm_kernel<2,2,2>", 9: "conv_gemm_kernel<1,1,4>", 10: "conv_stream_kernel", 11: "conv_pp_kernel", 12: "conv_win_kernel", 13: "conv_swin_kernel", 14: "resunit_fwd_kernel", 15: "resunit_bwd_kernel", 16: "conv_coop_kernel", 17: "conv_dual_k1_kernel"}
 
 
+def kernel_name(kid: int) -> str:
+    """Kernel ids of the convolution launches (include/gan_amd.h GA_KERNEL_*); the gathered-GEMM instantiations arrive as
+    0xMWNB | BUF << 16 (ga_conv_gemm_variant) and are named as a profiler names them."""
+    if kid >= 0x1000:
+        mi, wm, wn, nb = (kid >> 12) & 15, (kid >> 8) & 15, (kid >> 4) & 15, kid & 15
+        return f"conv_gemm_kernel<{mi},{wm},{wn},{nb},{'true' if kid & 0x10000 else 'false'}>"
+    return KERNEL_NAMES.get(kid, f"kernel_{kid}")
+
+
 def make_models(precision: str, device, seed: int):
     from gan_amd.lab3_codec_bridge import FrozenEncodec
     from gan_amd.lab3_codec_models import CodecLatentTranslator, MultiScaleWaveDiscriminator
@@ -281,7 +290,7 @@ def main():
                 r[0] += 1; r[1] += flops; r[2] += e0.elapsed_time(e1)
             print("kernel  (B, Cin, M, J, Lout, nphase, in_stride, pre_act)  launches  ms  TFLOP/s", file=sys.stderr)
             for key, r in sorted(rows.items(), key=lambda kv: -kv[1][2]):
-                print(f"{KERNEL_NAMES[key[0]]:26s} {str(key[1:]):44s} {r[0]:3d} {r[2]:8.3f} {r[1] / max(r[2], 1e-9) / 1e9:8.1f}", file=sys.stderr)
+                print(f"{kernel_name(key[0]):38s} {str(key[1:]):44s} {r[0]:3d} {r[2]:8.3f} {r[1] / max(r[2], 1e-9) / 1e9:8.1f}", file=sys.stderr)
         esz = 2 if args.precision == "bf16" else 4
         for kid, launched, e0, e1, shape, flops in prof:
             k = kernels.setdefault(kid, {"launches": 0, "flops": 0.0, "launched": 0.0, "ms": 0.0, "bytes": 0.0})
@@ -292,11 +301,11 @@ def main():
             b_, cin_, m_, j_, lout_, _nph, istr_ = shape[:7]
             # algorithmic bytes of one launch: the input window once, the packed weights once, the output once
             k["bytes"] += esz * (b_ * lout_ * max(1, istr_) * cin_ + m_ * j_ * cin_ + b_ * lout_ * m_)
-        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9, 11, 12)), key=lambda k: kernels[k]["ms"], default=None)
+        dom = max((k for k in kernels if k in (3, 4, 7, 8, 9, 11, 12) or k >= 0x1000), key=lambda k: kernels[k]["ms"], default=None)
         if dom is not None:
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": kernel_name(dom), "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                         "flops_per_launch_avg": k["flops"] / k["launches"],
@@ -304,7 +313,21 @@ def main():
                         "flops": "algorithmic (conv taps k, DFT K once); launched_TFLOP/s counts the padded taps of strided "
                                  "data gradients and the 3x-deep K of the bf16 hi/lo MR-STFT GEMM",
                         "algorithmic_bytes_per_launch_avg": k["bytes"] / k["launches"]}
-            roofline.update(pmc_traffic(KERNEL_NAMES[dom]))
+            roofline.update(pmc_traffic(kernel_name(dom)))
+            # the whole gathered-GEMM family (every conv_gemm_kernel instantiation + the ping-pong kernel) next to its dominant member
+            fam = [v for k, v in kernels.items() if k >= 0x1000 or k in (7, 8, 9, 11)]
+            fam_ms, fam_fl = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam)
+            # D blocks 2-4 alone (k41 stride-4 forward convs, their 11-tap folded data gradients), whichever kernel ran them: the
+            # layers the north star's ">= 50 % of peak on the G/D conv kernels" is about
+            dl = [(fl, e0.elapsed_time(e1)) for kid, _l, e0, e1, sh, fl in prof
+                  if (kid >= 0x1000 or kid == 11) and ((sh[3] == 41 and sh[6] == 4 and sh[1] >= 64) or (sh[3] == 11 and sh[6] == 1 and sh[1] >= 128))]
+            if dl:
+                d_fl, d_ms = sum(a for a, _ in dl), sum(b for _, b in dl)
+                roofline["d_blocks_2_4_fwd_dgrad"] = {"launches": len(dl), "ms": round(d_ms, 3), "TFLOP/s": round(d_fl / d_ms / 1e9, 2),
+                                                      "frac": round(d_fl / d_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+            roofline["gathered_gemm_family"] = {"launches": sum(v["launches"] for v in fam), "ms": round(fam_ms, 3),
+                                                "TFLOP/s": round(fam_fl / max(fam_ms, 1e-9) / 1e9, 2),
+                                                "frac": round(fam_fl / max(fam_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)}
 
     if rank == 0:
         total_samples = args.batch * world * args.steps
@@ -319,7 +342,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "random_init_weights": True},
             "roofline": roofline,
-            "kernel_breakdown": {KERNEL_NAMES[k]: {"launches": v["launches"], "ms": round(v["ms"], 3),
+            "kernel_breakdown": {kernel_name(k): {"launches": v["launches"], "ms": round(v["ms"], 3),
                                                     "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                                  for k, v in sorted(kernels.items())},
             "loss_g_last": round(loss_g, 5),

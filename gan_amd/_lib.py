@@ -103,6 +103,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
     "ga_conv_kernel_id": [C.POINTER(ConvParams), _I, _I],
+    "ga_conv_gemm_variant": [C.POINTER(ConvParams)],
     "ga_conv_suggest_ksplit": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
     "ga_conv_splitk_static": [C.POINTER(ConvParams), _I, _P],

@@ -14,6 +14,7 @@ int ga_conv_win_supported(const ConvParams& p);
 int ga_conv_win_wanted(const ConvParams& p);
 int ga_conv_coop_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
+int ga_conv_gemm_variant_impl(const ConvParams& p);
 int ga_conv_pp_supported(const ConvParams& p);
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
@@ -95,6 +96,8 @@ int ga_conv_splitk_static(const ga_conv_params* hp, int dtype, hipStream_t s) {
     if (!hp || dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
     return ga_conv_splitk_static_impl(*hp, s);
 }
+
+int ga_conv_gemm_variant(const ga_conv_params* hp) { return hp ? ga_conv_gemm_variant_impl(*hp) : 0; }
 
 int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (!hp) return -1;

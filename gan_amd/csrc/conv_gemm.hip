@@ -610,7 +610,7 @@ static int gemm_half_max_blocks() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GA_GEMM_HALF_MAX");
-        v = e ? atoi(e) : 128;
+        v = e ? atoi(e) : 400;  // (re-swept with buffer-load staging: 128 -> 400 is +0.5 % at B = 64 and at B = 12)
         if (v < 0) v = 0;
     }
     return v;
@@ -643,6 +643,15 @@ static int gemm_mgroup() {
     return v;
 }
 
+// buffer-load staging where it applies (zero padding, 32-bit byte offsets); GA_GEMM_BUF=0 keeps the flat form.
+// (Cin a multiple of the K-step: a K-step then lies inside ONE tap for every lane, which is what makes the K position
+// wave-uniform; with other channel counts the lanes of a K-step straddle taps and the flat form's per-lane state is needed)
+static bool gemm_use_buf(const ConvParams& p) {
+    const char* eb = getenv("GA_GEMM_BUF");
+    return !(eb && eb[0] == '0') && p.pad_mode == 0 && p.Cin % GBK == 0 &&
+           (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64 && (long)p.M * p.J * p.Cin * 2 < (1L << 31) - 64;
+}
+
 template <int MI, int WM, int WN, int NBUF>
 static int launch_gemm(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * 64;
@@ -658,12 +667,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
     size_t lds = NBUF * (BM + BN) * 128;
     const size_t epi = WM * WN * 32 * (MI * 32 + 4) * sizeof(float);
     if (lds < epi) lds = epi;
-    // buffer-load staging where it applies (zero padding, whole K-steps, 32-bit byte offsets); GA_GEMM_BUF=0 keeps the flat form
-    const char* eb = getenv("GA_GEMM_BUF");
-    // (Cin a multiple of the K-step: a K-step then lies inside ONE tap for every lane, which is what makes the K position
-    // wave-uniform; with other channel counts the lanes of a K-step straddle taps and the flat form's per-lane state is needed)
-    const bool buf = !(eb && eb[0] == '0') && p.pad_mode == 0 && p.Cin % GBK == 0 &&
-                     (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64 && (long)p.M * Ktot * 2 < (1L << 31) - 64;
+    const bool buf = gemm_use_buf(p);
     const int grid = (int)((total + 7) / 8 * 8);
     const int flags = ksplit > 1 ? (1 | (gemm_mgroup() & 0x10000)) : gemm_mgroup();
     // (two explicit launches: taking the address of the BUF = true instantiation into a function pointer fails to compile
@@ -685,6 +689,24 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
 
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
+
+// the instantiation conv_gemm_kernel<MI, WM, WN, NBUF> of a problem, as 0xMWNB
+static int gemm_variant(const ConvParams& p) {
+    // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
+    // wants the second buffer
+    const int ksteps = (p.J * p.Cin + GBK - 1) / GBK;
+    const int nb_small = gemm_nbuf_override() ? gemm_nbuf_override() : (ksteps <= 8 ? 1 : 2);
+    if (p.M <= 32) return nb_small == 1 ? 0x1141 : 0x1142;
+    if (p.M <= 64) return nb_small == 1 ? 0x2141 : 0x2142;
+    // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
+    // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
+    const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase * (p.ksplit > 1 ? p.ksplit : 1);
+    // few 128x128 tiles (short sequences: the generator's and the judge's convs): 64x128 tiles double the workgroups
+    if (blocks <= gemm_half_max_blocks() && !gemm_nbuf_override()) return (2 * blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 0x1224 : 0x1222;
+    int nbuf = gemm_nbuf_override();
+    if (!nbuf) nbuf = blocks >= gemm_single_min_blocks() ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
+    return 0x2220 | nbuf;
+}
 int ga_conv_win_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_coop_wanted(const ConvParams& p);
@@ -698,23 +720,24 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (ga_conv_coop_wanted(p)) return ga_conv_coop_impl(p, s);  // many rows, K of a few hundred, 256 channels: weights in registers (conv_coop.hip)
     if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
     if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
-    // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
-    // wants the second buffer
-    const int ksteps = (p.J * p.Cin + GBK - 1) / GBK;
-    const int nb_small = gemm_nbuf_override() ? gemm_nbuf_override() : (ksteps <= 8 ? 1 : 2);
-    if (p.M <= 32) return nb_small == 1 ? launch_gemm<1, 1, 4, 1>(p, s) : launch_gemm<1, 1, 4, 2>(p, s);
-    if (p.M <= 64) return nb_small == 1 ? launch_gemm<2, 1, 4, 1>(p, s) : launch_gemm<2, 1, 4, 2>(p, s);
-    // 128x128: one LDS buffer (32 KiB, three workgroups per CU hide each other's loads) once the grid is several
-    // waves of workgroups deep; two buffers (own prefetch) when the grid is about one workgroup per CU or less
-    const long blocks = (((long)p.B * p.Lout + 127) / 128) * ((p.M + 127) / 128) * p.nphase * (p.ksplit > 1 ? p.ksplit : 1);
-    // few 128x128 tiles (short sequences: the generator's and the judge's convs): 64x128 tiles double the workgroups
-    if (blocks <= gemm_half_max_blocks() && !gemm_nbuf_override()) {
-        if (2 * blocks <= gemm_deep_max_blocks() && ksteps >= 6) return launch_gemm<1, 2, 2, 4>(p, s);
-        return launch_gemm<1, 2, 2, 2>(p, s);
+    switch (gemm_variant(p)) {
+        case 0x1141: return launch_gemm<1, 1, 4, 1>(p, s);
+        case 0x1142: return launch_gemm<1, 1, 4, 2>(p, s);
+        case 0x2141: return launch_gemm<2, 1, 4, 1>(p, s);
+        case 0x2142: return launch_gemm<2, 1, 4, 2>(p, s);
+        case 0x1224: return launch_gemm<1, 2, 2, 4>(p, s);
+        case 0x1222: return launch_gemm<1, 2, 2, 2>(p, s);
+        case 0x2221: return launch_gemm<2, 2, 2, 1>(p, s);
+        case 0x2224: return launch_gemm<2, 2, 2, 4>(p, s);
+        default: return launch_gemm<2, 2, 2, 2>(p, s);
     }
-    int nbuf = gemm_nbuf_override();
-    if (!nbuf) nbuf = blocks >= gemm_single_min_blocks() ? 1 : (blocks <= gemm_deep_max_blocks() && ksteps >= 6) ? 4 : 2;
-    return nbuf == 1 ? launch_gemm<2, 2, 2, 1>(p, s) : nbuf == 4 ? launch_gemm<2, 2, 2, 4>(p, s) : launch_gemm<2, 2, 2, 2>(p, s);
+}
+
+// which conv_gemm_kernel<MI, WM, WN, NBUF, BUF> a problem runs on, as 0xMWNB | BUF << 16 (0: another kernel takes it).  For the
+// benchmark's per-kernel accounting: the instantiations are different kernels to a profiler (ga_conv_gemm_variant in gan_amd.h).
+int ga_conv_gemm_variant_impl(const ConvParams& p) {
+    if (!ga_conv_gemm_supported(p) || ga_conv_coop_wanted(p) || ga_conv_win_wanted(p) || ga_conv_pp_wanted(p)) return 0;
+    return gemm_variant(p) | (gemm_use_buf(p) ? 0x10000 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------

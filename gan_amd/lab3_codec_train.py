@@ -256,13 +256,16 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
 # Frozen decodes on a side stream beside the generator pass and the decode of q_hat: 48.25 -> 47.6 ms per step at B = 64 (same-box
 # A/B).  Starting them a whole iteration ahead (while the previous D / G steps run) was measured too: 48.6 -> 48.2 only -- the step
 # is throughput-bound there, and the persistent LSTM's 96 KiB of LDS per CU halves the co-resident GEMM workgroups -- not kept.
+# Only from 32 samples per batch up: at the reference's default batch of 12 the joint pass wins (one LSTM launch over 48 items
+# instead of two over 36 and 12: 15.7 vs 16.5 ms per step).
 ASYNC_FROZEN_DECODE = os.environ.get("GA_ASYNC_FROZEN", "1") == "1"
+ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "32"))
 
 
-def _frozen_decode_stream(codec, device):
-    """The side stream of the frozen decodes, or None (off, not a GPU codec, or the codec's first iteration: its packed
-    weights and LSTM layouts are built lazily by the first decode, which therefore runs on the main stream alone)."""
-    if not ASYNC_FROZEN_DECODE or device.type != "cuda" or not hasattr(codec, "decode_embeddings_mixed"):
+def _frozen_decode_stream(codec, device, batch: int):
+    """The side stream of the frozen decodes, or None (off, small batch, not a GPU codec, or the codec's first iteration: its
+    packed weights and LSTM layouts are built lazily by the first decode, which therefore runs on the main stream alone)."""
+    if not ASYNC_FROZEN_DECODE or batch < ASYNC_FROZEN_MIN_BATCH or device.type != "cuda" or not hasattr(codec, "decode_embeddings_mixed"):
         return None
     st = getattr(codec, "_frozen_side_stream", None)
     if st is None:
@@ -294,7 +297,7 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
     # third of the (launch-bound) LSTM steps.
     B0 = int(q_src.shape[0])
     frozen_list = [q_src] + ([q_real_tgt] if take_d_step else []) + [q_real_tgt_g]
-    side = _frozen_decode_stream(codec, device)
+    side = _frozen_decode_stream(codec, device, B0)
     if side is not None:
         # The frozen decodes depend on the batch alone, not on G: they start on a side stream BEFORE the generator pass and run
         # beside it and beside the decode of q_hat (their LSTM is latency-bound, the generator's small convolutions are too, the

@@ -153,6 +153,11 @@ def _launch_conv(p: L.ConvParams, x: Tensor, w: Tensor, y: Tensor, bias=None, re
         return
     # benchmark accounting: HIP events on the launch stream around this one launch + its multiply-adds as launched
     kid = L.lib().ga_conv_kernel_id(C.byref(p), L.dt(x), impl)
+    if kid in (7, 8, 9) and impl in (L.IMPL_AUTO, L.IMPL_MFMA):
+        # the gathered-GEMM instantiations are different kernels to a profiler: account for them one by one (kid >= 0x1000)
+        var = L.lib().ga_conv_gemm_variant(C.byref(p))
+        if var:
+            kid = var
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     L.check(L.lib().ga_conv(C.byref(p), L.dt(x), impl, L.stream()), "ga_conv")

@@ -174,6 +174,10 @@ int ga_conv_splitk_static(const ga_conv_params* h_params, int dtype, ga_stream_t
 #define GA_KERNEL_COOP 16        /* conv_coop_kernel: 256 output channels, K = 2 x 128, many rows: weights in the registers of an
                                     eight-wave workgroup, shared input window (the decoder's transposed conv 128 -> 4 x 64) */
 int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
+/* Which instantiation conv_gemm_kernel<MI, WM, WN, NBUF, BUF> ga_conv would run the problem on with GA_IMPL_AUTO / GA_IMPL_MFMA
+ * (bf16), as 0xMWNB | BUF << 16: tile rows per wave (MI x 32), waves along m / n, LDS buffers, buffer-load staging.  0: another
+ * kernel takes it.  The instantiations are different kernels to a profiler; bench.py's per-kernel accounting asks this. */
+int ga_conv_gemm_variant(const ga_conv_params* h_params);
 
 /* One SEANet residual unit of the frozen decoder, forward, as ONE pass over its input (bf16):
  *     y = shortcut(x) + conv_k1(ELU(conv_k3(ELU(x))))          C -> C/2 -> C channels, causal k3 with reflect-left padding

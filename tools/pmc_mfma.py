@@ -16,10 +16,10 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.match(r"void (conv_gemm_kernel<\d+, \d+, \d+), \d+>", name)
+    # gathered-GEMM instantiations keep their template arguments (they are different kernels: bench.py names them the same way)
+    m = re.match(r"void (conv_gemm_kernel<[^>]*>)", name)
     if m:
-        k = m.group(1).replace(" ", "") + ">"
-        return "conv_gemm_kernel<2,2,2>" if k == "conv_gemm_kernel<1,2,2>" else k
+        return m.group(1).replace(" ", "")
     m = re.match(r"void ([a-z0-9_]+_kernel)", name)
     if m:
         return m.group(1)

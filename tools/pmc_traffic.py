@@ -15,12 +15,10 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.match(r"void (conv_gemm_kernel<\d+, \d+, \d+), \d+>", name)
+    # gathered-GEMM instantiations keep their template arguments (they are different kernels: bench.py names them the same way)
+    m = re.match(r"void (conv_gemm_kernel<[^>]*>)", name)
     if m:
-        k = m.group(1).replace(" ", "") + ">"
-        # the 64x128-tile instantiation serves the same problems (kernel id GA_KERNEL_GEMM_128x128, few-workgroup grids):
-        # bench.py counts both under one name, so does this summary
-        return "conv_gemm_kernel<2,2,2>" if k == "conv_gemm_kernel<1,2,2>" else k
+        return m.group(1).replace(" ", "")
     m = re.match(r"_Z\d+([a-z0-9_]+_kernel)", name)
     if m:
         return m.group(1)
