@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--stft-stress", action="store_true", help="BASELINE config 5: the six MR-STFT resolutions (256 ... 8192) of SURVEY.md "
                     "8(d); use with --frames 2250 (30 s clips, S = 720000) and a batch sized for the 288 GB of HBM")
     ap.add_argument("--no-fp32-batch12", action="store_true", help="skip the fp32-mode leg (B=12, the rtol-1e-4 parity path) reported under 'fp32_batch12'")
+    ap.add_argument("--no-stage2", action="store_true", help="skip the stage-2-like leg (d_step_period=2, R1 every 16 steps, gamma=1: SURVEY.md "
+                    "8(d) config 2 reports it separately from the period-1 / no-R1 headline) reported under 'stage2_like'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
@@ -207,7 +209,7 @@ def main():
         dp.broadcast_params(opt_g, opt_d)
     gen = torch.Generator().manual_seed(328 + rank)
 
-    state = {"batches": None, "i": 0, "models": (G, D, codec, opt_g, opt_d)}
+    state = {"batches": None, "i": 0, "models": (G, D, codec, opt_g, opt_d), "cfg": scfg}
 
     def step(_i=None):
         i = state["i"]
@@ -215,7 +217,7 @@ def main():
         batches = state["batches"]
         b = batches[i % len(batches)]
         G_, D_, codec_, og_, od_ = state["models"]
-        return codec_train_iteration(scfg, G_, D_, codec_, og_, od_, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
+        return codec_train_iteration(state["cfg"], G_, D_, codec_, og_, od_, b[0], b[1], b[2], b[3], b[4], b[5], global_step=i + 1, dp=dp)
 
     def barrier():
         if dp is not None:
@@ -264,6 +266,18 @@ def main():
         state["models"] = (G, D, codec, opt_g, opt_d)
         del G32, D32, codec32, og32, od32
         torch.cuda.empty_cache()
+    # stage-2-like schedule (run_lab3_codec.py:276-279: D step every second iteration, R1 with gamma 1 every 16th), 16 iterations so
+    # that exactly one R1 step is inside the timed region
+    stage2 = None
+    if not args.no_stage2 and not args.stft_stress:
+        import dataclasses
+        state["cfg"] = dataclasses.replace(scfg, d_step_period=2, r1_gamma=1.0, r1_interval=16)
+        state["i"] = 0
+        el2, _ = measure(args.batch, steps=16, warmup=2)
+        stage2 = {"d_step_period": 2, "r1_interval": 16, "r1_gamma": 1.0, "batch_per_gpu": args.batch, "steps": 16, "warmup": 2,
+                  "value": round(args.batch * world * 16 / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / 16, 3)}
+        state["cfg"] = scfg
+        state["i"] = 0
     batch12 = None
     if args.batch != 12 and not args.no_batch12:  # the reference's default batch size, second line of the report
         el12, _ = measure(12)
@@ -352,6 +366,8 @@ def main():
             line["batch12"] = batch12
         if fp32_b12 is not None:
             line["fp32_batch12"] = fp32_b12
+        if stage2 is not None:
+            line["stage2_like"] = stage2
         line["config"]["note"] = ("headline batch is 64 per GPU since round 2 (round 1's BENCH line was B=12): compare rounds on "
                                   "'batch12', the reference's default batch, which every run reports")
         if world == 1 and not args.no_cpu_baseline:

@@ -3,7 +3,7 @@
 # One rocprofv3 run per pass: kernel trace + stats, then FETCH_SIZE, WRITE_SIZE and the MFMA-busy counters, each alone.
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-args="--steps 6 --warmup 2 --no-cpu-baseline --no-batch12 --no-fp32-batch12 $*"
+args="--steps 6 --warmup 2 --no-cpu-baseline --no-batch12 --no-fp32-batch12 --no-stage2 $*"
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt -o p -- python3 bench.py $args > $out/kt.log 2>&1 || { echo "kernel trace failed"; tail -5 $out/kt.log; exit 1; }
