@@ -46,7 +46,7 @@ def test_bf16_generator_gradient_is_a_descent_direction_for_the_default_loss():
     cos = float(torch.dot(g_bf, g_ref) / (g_bf.norm() * g_ref.norm()))
     print(f"bf16 G gradient vs fp32 oracle, default loss (MR-STFT weight 2.0): cosine {cos:.4f}, "
           f"norms {float(g_bf.norm()):.4f} / {float(g_ref.norm()):.4f}")
-    assert cos > 0.1, cos  # measured 0.2-0.3: the MR-STFT part is noise-like in every precision, the rest is tracked
+    assert cos > 0.1, cos  # measured 0.74: the MR-STFT part is noise-like in every precision, the rest is tracked
     # fp32-evaluated loss along the bf16 direction (unit vector u, step eta in parameter space)
     u = g_bf / g_bf.norm()
     slope = float(torch.dot(u, g_ref))  # first-order decrease per unit step, by the oracle's own gradient
