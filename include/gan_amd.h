@@ -55,7 +55,8 @@ typedef struct ihipStream_t* ga_stream_t; /* == hipStream_t */
                                  GA_IMPL_AUTO reaches conv_mfma_kernel only for shapes the gathered kernel refuses (ELU on load with
                                  fp32 output, M % 8 != 0) and never reaches wgrad_mfma_kernel */
 #define GA_IMPL_MFMA_PP 4     /* force the ping-pong gathered-GEMM kernel (conv_pp_kernel: 256x256 tiles, eight waves); error if
-                                 unsupported.  AUTO / MFMA pick it by themselves for deep-K layers with >= 192 output channels */
+                                 unsupported (needs zero padding, Cin % 64 == 0, tensors < 2^31 bytes).  AUTO / MFMA pick it for K = J * Cin >= 8192 with
+                                 >= 192 tiles of 256 x 256 (D blocks.4 forward at the bench batch) */
 
 #define GA_IMPL_MFMA_LDSWIN 5 /* force the LDS-window kernel of the narrow-channel D layers (conv_win_kernel: the input rows of a
                                  tile staged once in LDS, every tap read from there); error if unsupported.  AUTO / MFMA pick it
