@@ -104,6 +104,7 @@ _SIGNATURES = {
     "ga_conv": [C.POINTER(ConvParams), _I, _I, _P],
     "ga_conv_kernel_id": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_gemm_variant": [C.POINTER(ConvParams)],
+    "ga_set_gemm_lds_budget": [C.c_int],
     "ga_conv_suggest_ksplit": [C.POINTER(ConvParams), _I, _I],
     "ga_conv_finish": [C.POINTER(ConvParams), _I, _P],
     "ga_conv_splitk_static": [C.POINTER(ConvParams), _I, _P],

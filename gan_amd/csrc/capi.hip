@@ -15,6 +15,7 @@ int ga_conv_win_wanted(const ConvParams& p);
 int ga_conv_coop_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_variant_impl(const ConvParams& p);
+int ga_set_gemm_lds_budget_impl(int bytes);
 int ga_conv_pp_supported(const ConvParams& p);
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
@@ -98,6 +99,7 @@ int ga_conv_splitk_static(const ga_conv_params* hp, int dtype, hipStream_t s) {
 }
 
 int ga_conv_gemm_variant(const ga_conv_params* hp) { return hp ? ga_conv_gemm_variant_impl(*hp) : 0; }
+int ga_set_gemm_lds_budget(int bytes) { return ga_set_gemm_lds_budget_impl(bytes); }
 
 int ga_conv_kernel_id(const ga_conv_params* hp, int dtype, int impl) {
     if (!hp) return -1;

@@ -690,8 +690,32 @@ static int launch_gemm(const ConvParams& p, hipStream_t s) {
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
 
+// LDS budget per workgroup for gathered-GEMM launches (0: none), see ga_set_gemm_lds_budget in gan_amd.h: a caller that runs these
+// launches BESIDE a persistent LSTM launch (one workgroup of ~111-137 KiB of LDS on every CU) bounds their LDS so that the two
+// co-reside on a CU instead of the GEMM waiting for the LSTM to leave.  A process-wide setting, read at launch time.
+static int g_gemm_lds_budget = 0;
+int ga_set_gemm_lds_budget_impl(int bytes) {
+    const int old = g_gemm_lds_budget;
+    g_gemm_lds_budget = bytes > 0 ? bytes : 0;
+    return old;
+}
+static int gemm_variant_lds(int v) {
+    const int mi = (v >> 12) & 15, wm = (v >> 8) & 15, wn = (v >> 4) & 15, nb = v & 15;
+    const int lds = nb * (wm * mi * 32 + wn * 64) * 128, epi = wm * wn * 32 * (mi * 32 + 4) * 4;
+    return lds > epi ? lds : epi;
+}
+
+static int gemm_variant_unbounded(const ConvParams& p);
 // the instantiation conv_gemm_kernel<MI, WM, WN, NBUF> of a problem, as 0xMWNB
 static int gemm_variant(const ConvParams& p) {
+    const int v = gemm_variant_unbounded(p);
+    const int budget = g_gemm_lds_budget;
+    if (budget <= 0 || gemm_variant_lds(v) <= budget) return v;
+    // the smallest configuration: 64 x 128 tile, one buffer = 24 KiB (only layers with M > 64 have it; others keep their choice)
+    if (p.M > 64 && gemm_variant_lds(0x1221) <= budget) return 0x1221;
+    return v;
+}
+static int gemm_variant_unbounded(const ConvParams& p) {
     // thin layers: short K (a few steps) is HBM-bound and wants occupancy (one buffer, 4 workgroups per CU); long K
     // wants the second buffer
     const int ksteps = (p.J * p.Cin + GBK - 1) / GBK;
@@ -717,9 +741,10 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
     if (p.res_mode == GA_RES_ADD_THEN_ACT && (!p.res || p.ksplit > 1 || p.dact_mode)) return GA_ERR_ARG;
     if (p.y2 && (p.ksplit > 1 || p.out_f32 || ((uintptr_t)p.y2 & 15))) return GA_ERR_ARG;
     if (p.Lout == 0) return GA_OK;
-    if (ga_conv_coop_wanted(p)) return ga_conv_coop_impl(p, s);  // many rows, K of a few hundred, 256 channels: weights in registers (conv_coop.hip)
-    if (ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
-    if (ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
+    const bool bounded = g_gemm_lds_budget > 0;  // (the special-shape kernels below all need more LDS than any budget worth setting)
+    if (!bounded && ga_conv_coop_wanted(p)) return ga_conv_coop_impl(p, s);  // many rows, K of a few hundred, 256 channels: weights in registers (conv_coop.hip)
+    if (!bounded && ga_conv_win_wanted(p)) return ga_conv_win_impl(p, s);  // narrow-channel D layers: input window staged once in LDS (conv_win.hip)
+    if (!bounded && ga_conv_pp_wanted(p)) return ga_conv_pp_impl(p, s);  // deep-K, >= 192-channel layers: the ping-pong kernel (conv_pp.hip)
     switch (gemm_variant(p)) {
         case 0x1141: return launch_gemm<1, 1, 4, 1>(p, s);
         case 0x1142: return launch_gemm<1, 1, 4, 2>(p, s);
@@ -727,6 +752,7 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
         case 0x2142: return launch_gemm<2, 1, 4, 2>(p, s);
         case 0x1224: return launch_gemm<1, 2, 2, 4>(p, s);
         case 0x1222: return launch_gemm<1, 2, 2, 2>(p, s);
+        case 0x1221: return launch_gemm<1, 2, 2, 1>(p, s);
         case 0x2221: return launch_gemm<2, 2, 2, 1>(p, s);
         case 0x2224: return launch_gemm<2, 2, 2, 4>(p, s);
         default: return launch_gemm<2, 2, 2, 2>(p, s);
@@ -736,7 +762,8 @@ int ga_conv_gemm_impl(const ConvParams& p, hipStream_t s) {
 // which conv_gemm_kernel<MI, WM, WN, NBUF, BUF> a problem runs on, as 0xMWNB | BUF << 16 (0: another kernel takes it).  For the
 // benchmark's per-kernel accounting: the instantiations are different kernels to a profiler (ga_conv_gemm_variant in gan_amd.h).
 int ga_conv_gemm_variant_impl(const ConvParams& p) {
-    if (!ga_conv_gemm_supported(p) || ga_conv_coop_wanted(p) || ga_conv_win_wanted(p) || ga_conv_pp_wanted(p)) return 0;
+    if (!ga_conv_gemm_supported(p)) return 0;
+    if (g_gemm_lds_budget <= 0 && (ga_conv_coop_wanted(p) || ga_conv_win_wanted(p) || ga_conv_pp_wanted(p))) return 0;
     return gemm_variant(p) | (gemm_use_buf(p) ? 0x10000 : 0);
 }
 

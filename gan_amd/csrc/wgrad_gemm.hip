@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     // with xcd_order the ids an XCD receives are consecutive work items instead.  Measured at B = 128: +8-16 % on the 64 x 256
     // tiles of D blocks.1, +2 % / -4 % / 0 on blocks 2 / 3 / 4 with 128 x 128 tiles: on for the former only (GA_WGRAD_XCD=2: all).
     int wk = blockIdx.x;
-    if (xcd_order) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
+    // (bits 8-10 of xcd_order: measurement-only ablations, results invalid -- GA_WGRAD_ABL: 1 no loads after a slice's first step,
+    // 2 no fragment reads after the first step, 4 rows do not advance)
+    const bool abl_noload = xcd_order & 0x100, abl_noread = xcd_order & 0x200, abl_noadv = xcd_order & 0x400;
+    if (xcd_order & 0xff) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
     if (wk >= total) return;
     const int bx = wk % base, by = wk / base;
     // NB = 2: the G tile has 64 columns; reduction rows n and n + 32 share one 256-byte LDS row (n + 32 in its second half), so
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
                     const bool ok = n_ok && b_ok[sb] && (unsigned)(rt[i] * S + bdR[sb]) < (unsigned)p.Lin;
                     if (!b_one[sb]) wg_bglds16(rsX, bb + sb * WGG_TILE + i * 4096, ok ? xrow[i] + xcol[sb] : OOB);
                 }
+                if (abl_noadv) continue;
                 rt[i] += WGG_RK;
                 grow[i] += g_step;
                 xrow[i] += x_step;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         const int buf = NBUF == 2 ? (st - s_begin) & 1 : 0;
         if (NBUF == 1) {
             if (st > s_begin) __syncthreads();  // everyone is done reading the single buffer
-            issue(0);
+            if (!(abl_noload && st > s_begin)) issue(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -258,10 +262,11 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         if (wave_active) {
             const char* Ab = Al + buf * ATILE;
             const char* Bb = Bl + (buf * NB + bsub) * WGG_TILE;
+            bf16x8 a[2], b[2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 if (kk < kk0 || kk >= kk1) continue;
-                bf16x8 a[2], b[2];
+                if (!(abl_noread && st > s_begin)) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const char* ap = NB == 2 ? Ab + (kk & 1) * 4096 + (kk < 2 ? offA[mi] : offA2[mi]) : Ab + kk * 4096 + offA[mi];
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) b[ni] = wg_tr_frag(Bb + kk * 4096 + offB[ni], Bb + kk * 4096 + offB[ni] + 1024);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -400,12 +406,17 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
         const char* e = getenv("GA_WGRAD_NBUF");
         nbuf = (e && e[0] == '2') ? 2 : 1;  // single buffer by default: 20-40 % faster on every D layer (B = 24 and 128)
     }
-    static int xcd = -1;
-    if (xcd < 0) {
+    int xcd = 1;  // (read per launch: same-process A/B)
+    {
         const char* e = getenv("GA_WGRAD_XCD");
-        xcd = e ? atoi(e) : 1;
+        if (e) xcd = atoi(e);
     }
-    const int xcd_wide = xcd >= 1, xcd_all = xcd >= 2;
+    int abl = 0;
+    {
+        const char* e = getenv("GA_WGRAD_ABL");
+        if (e) abl = (atoi(e) & 7) << 8;
+    }
+    const int xcd_wide = (xcd >= 1) | abl, xcd_all = (xcd >= 2) | abl;
     const long total = base * splits;
     if (total > (1L << 30)) return GA_ERR_ARG;
     const unsigned grid = (unsigned)((total + 7) / 8 * 8);

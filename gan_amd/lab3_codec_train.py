@@ -260,6 +260,7 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
 # instead of two over 36 and 12: 15.7 vs 16.5 ms per step).
 ASYNC_FROZEN_DECODE = os.environ.get("GA_ASYNC_FROZEN", "1") == "1"
 ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "32"))
+ASYNC_GEMM_LDS_BUDGET = int(os.environ.get("GA_ASYNC_GEMM_LDS", str(25 * 1024)))  # 0: the generator's convs keep their usual tiles
 
 
 def _frozen_decode_stream(codec, device, batch: int):
@@ -306,8 +307,16 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             frozen_out = codec.decode_embeddings(torch.cat(frozen_list, dim=0))
-        q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
-                          style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+        # The side stream's LSTM launch holds one workgroup with 111-137 KiB of LDS on every CU for ~2 ms; the generator's small
+        # convolutions share the CUs with it when their workgroups fit into what is left (24 KiB tiles), instead of queueing
+        # behind it (rocprofv3 timeline: the generator's first conv waited 2.2 ms for the LSTM to leave).
+        prev_budget = L.lib().ga_set_gemm_lds_budget(ASYNC_GEMM_LDS_BUDGET) if ASYNC_GEMM_LDS_BUDGET > 0 else None
+        try:
+            q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
+                              style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+        finally:
+            if prev_budget is not None:
+                L.lib().ga_set_gemm_lds_budget(prev_budget)
         x_hat = codec.decode_embeddings(q_hat)
         main.wait_stream(side)
         frozen_out.record_stream(main)

@@ -179,6 +179,13 @@ int ga_conv_kernel_id(const ga_conv_params* h_params, int dtype, int impl);
  * (bf16), as 0xMWNB | BUF << 16: tile rows per wave (MI x 32), waves along m / n, LDS buffers, buffer-load staging.  0: another
  * kernel takes it.  The instantiations are different kernels to a profiler; bench.py's per-kernel accounting asks this. */
 int ga_conv_gemm_variant(const ga_conv_params* h_params);
+/* LDS budget per workgroup, in bytes, for the gathered-GEMM launches ga_conv makes from now on (0: none; returns the previous
+ * value).  For callers that run small convolutions on one stream BESIDE a persistent LSTM launch (ga_lstm_fwd with a workspace: one
+ * workgroup holding 111-137 KiB of LDS on every CU) on another: with 24 KiB <= budget < 32 KiB the launches take the 64 x 128,
+ * single-buffer configuration (24 KiB) and share the CUs with the LSTM's workgroups instead of queueing behind them.  Results do
+ * not depend on it.  Process-wide and not synchronised: set it from the thread that launches (the reference has no counterpart:
+ * lab3_codec_train.py:404-470 runs everything on one stream). */
+int ga_set_gemm_lds_budget(int bytes);
 
 /* One SEANet residual unit of the frozen decoder, forward, as ONE pass over its input (bf16):
  *     y = shortcut(x) + conv_k1(ELU(conv_k3(ELU(x))))          C -> C/2 -> C channels, causal k3 with reflect-left padding

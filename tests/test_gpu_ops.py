@@ -214,6 +214,34 @@ def test_buffer_load_staging_is_bit_identical_to_flat_addresses(case, monkeypatc
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), "weight gradient"
 
 
+def test_gemm_lds_budget_changes_the_tile_not_the_result():
+    """ga_set_gemm_lds_budget: under a 25 KiB budget the generator-sized gathered GEMMs (256 -> 256 channels, k3, 64 x 375 rows) and a
+    128 x 128-tile layer take the 64 x 128 single-buffer configuration (0x1221) so that they fit beside a persistent LSTM workgroup;
+    same K order, same accumulation order: bit-identical outputs, and the setter returns the previous value."""
+    import ctypes as C
+    torch.manual_seed(23)
+    for g, B, Ln in ((ConvGeom("conv", 256, 256, 3, 1, 2, 2), 8, 375), (ConvGeom("conv", 128, 256, 41, 4, 20, 1), 16, 7500)):
+        x = torch.randn(B, Ln, g.cin, device=DEV).bfloat16()
+        w = torch.randn(*g.wdims, device=DEV) / (g.cin * g.k) ** 0.5
+        bias = torch.randn(g.cout, device=DEV)
+        wf = ops.pack_weight(g, w, g.fwd_pack, torch.bfloat16)
+        p = ops.fwd_params(g, B, Ln)
+        ops.set_conv_impl(L.IMPL_MFMA)
+        try:
+            v0 = L.lib().ga_conv_gemm_variant(C.byref(p)) & 0xffff
+            y0 = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU)
+            assert L.lib().ga_set_gemm_lds_budget(25 * 1024) == 0
+            try:
+                v1 = L.lib().ga_conv_gemm_variant(C.byref(p)) & 0xffff
+                y1 = ops.conv_forward(g, x, wf, bias, post_act=L.ACT_LRELU)
+            finally:
+                assert L.lib().ga_set_gemm_lds_budget(0) == 25 * 1024
+        finally:
+            ops.set_conv_impl(L.IMPL_AUTO)
+        assert v0 != 0x1221 and v1 == 0x1221, (hex(v0), hex(v1))
+        assert torch.equal(y0, y1)
+
+
 def test_ping_pong_kernel_is_bit_identical_to_the_gathered_kernel():
     """conv_pp_kernel (256 x 256 tiles, eight waves, 16x16x32 MFMAs, buffer-load staging, phase-fast taps) on the shapes AUTO
     gives it (D blocks.4 forward, K = 10496) and on a folded data gradient: same K order and per-output accumulation order

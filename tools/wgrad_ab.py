@@ -1,4 +1,5 @@
-"""In-process A/B of the weight-gradient kernel: flat-address vs buffer-load staging (GA_WGRAD_BUF), bit-compared."""
+"""In-process A/B of the weight-gradient kernel, results compared against the first variant.  Default: flat-address vs
+buffer-load staging (GA_WGRAD_BUF); WG_AB_VARIANTS="label:K=V,K=V;label2:..." sets other environments (read per launch)."""
 import os, sys, statistics, torch
 sys.path.insert(0, ".")
 from gan_amd import _lib as L, ops
@@ -17,23 +18,30 @@ def timeit(fn, n=8):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-tot = {"0": 0.0, "1": 0.0}
+VARS = [("flat", {"GA_WGRAD_BUF": "0"}), ("buf", {"GA_WGRAD_BUF": "1"})]
+if os.environ.get("WG_AB_VARIANTS"):
+    VARS = [(it.split(":")[0], dict(kv.split("=") for kv in it.split(":")[1].split(",") if kv)) for it in os.environ["WG_AB_VARIANTS"].split(";")]
+KEYS = sorted({k for _, e in VARS for k in e})
+tot = {lab: 0.0 for lab, _ in VARS}
 torch.manual_seed(0)
 for name, g, Ln, B in cases:
     x = torch.randn(B, Ln, g.cin, device="cuda").bfloat16()
     Lo = g.out_len(Ln)
     gy = torch.randn(B, Lo, g.cout, device="cuda").bfloat16()
     flops = 2.0 * B * Lo * g.cout * g.cin * g.k
-    res, times = {}, {"0": [], "1": []}
+    res, times = {}, {lab: [] for lab, _ in VARS}
     for rnd in range(3):
-        for v in ("0", "1"):
-            os.environ["GA_WGRAD_BUF"] = v
+        for lab, env in VARS:
+            for k in KEYS: os.environ.pop(k, None)
+            os.environ.update(env)
             if rnd == 0:
                 out = ops.conv_wgrad(g, gy, x)
-                res[v] = [t.float().clone() for t in (out if isinstance(out, (tuple, list)) else [out]) if t is not None]
-            times[v].append(timeit(lambda: ops.conv_wgrad(g, gy, x)))
-    err = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(res["1"], res["0"]))
-    t0, t1 = statistics.median(times["0"]), statistics.median(times["1"])
-    tot["0"] += t0; tot["1"] += t1
-    print(f"{name:8s} Cin{g.cin:4d} M{g.cout:4d} B{B} Lout{Lo:6d} | flat {t0*1e3:7.1f}us {flops/t0/1e9:5.0f}TF | buf {t1*1e3:7.1f}us {flops/t1/1e9:5.0f}TF | rel diff {err:.1e}", flush=True)
+                res[lab] = [t.float().clone() for t in (out if isinstance(out, (tuple, list)) else [out]) if t is not None]
+            times[lab].append(timeit(lambda: ops.conv_wgrad(g, gy, x)))
+    row = f"{name:8s} Cin{g.cin:4d} M{g.cout:4d} B{B} Lout{Lo:6d} |"
+    for lab, _ in VARS:
+        t = statistics.median(times[lab]); tot[lab] += t
+        err = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(res[lab], res[VARS[0][0]]))
+        row += f" {lab} {t*1e3:7.1f}us {flops/t/1e9:5.0f}TF d{err:.0e} |"
+    print(row, flush=True)
 print("total ms", tot)
