@@ -74,10 +74,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     // with xcd_order the ids an XCD receives are consecutive work items instead.  Measured at B = 128: +8-16 % on the 64 x 256
     // tiles of D blocks.1, +2 % / -4 % / 0 on blocks 2 / 3 / 4 with 128 x 128 tiles: on for the former only (GA_WGRAD_XCD=2: all).
     int wk = blockIdx.x;
-    // (bits 8-10 of xcd_order: measurement-only ablations, results invalid -- GA_WGRAD_ABL: 1 no loads after a slice's first step,
-    // 2 no fragment reads after the first step, 4 rows do not advance)
-    const bool abl_noload = xcd_order & 0x100, abl_noread = xcd_order & 0x200, abl_noadv = xcd_order & 0x400;
-    if (xcd_order & 0xff) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
+    if (xcd_order) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
     if (wk >= total) return;
     const int bx = wk % base, by = wk / base;
     // NB = 2: the G tile has 64 columns; reduction rows n and n + 32 share one 256-byte LDS row (n + 32 in its second half), so
@@ -152,6 +149,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
                         *(uint4*)(Bl + buf * NB * WGG_TILE + wid * 1024 + sb * WGG_TILE + i * 4096 + lane * 16) = make_uint4(0x00003F80u, 0u, 0u, 0u);
             }
     }
+    const unsigned am2x = (unsigned)am * 2u;
+    // workgroup-uniform: does this k-tile hold the bias column (only the last one can), does a step cross at most one item boundary
+    const bool tile_has_one = p.dbias && kbase <= Ktot && Ktot < kbase + 128 * NB;
+    const bool single_wrap = p.Lout >= WGG_RK;
     const unsigned g_step = (unsigned)(WGG_RK * p.M) * 2u, g_wrap = (unsigned)((p.LgTot - p.Lout) * p.M) * 2u;
     const unsigned x_step = (unsigned)(WGG_RK * S * Cin) * 2u, x_wrap = (unsigned)((p.Lin - p.Lout * S) * Cin) * 2u;
 
@@ -169,24 +170,53 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
                     wg_bglds16(rsG, ab + i * 4096, (b_ < p.B && (lpiece & 7) * 8 < p.M) ? go + am2b : OOB);
                 }
             }
+            // (the two conditions below are workgroup-uniform: the straight-line forms carry no exec-mask regions and no loops;
+            // measured: no change in kernel time -- the staging instructions are not what bounds this kernel -- kept for the ISA)
+            if (!tile_has_one) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool n_ok = rb[i] < p.B;
-                if (NB == 1) wg_bglds16(rsG, ab + i * 4096, (n_ok && a_ok) ? grow[i] + (unsigned)am * 2u : OOB);
+                for (int i = 0; i < 4; ++i) {
+                    const bool n_ok = rb[i] < p.B;
+                    if (NB == 1) wg_bglds16(rsG, ab + i * 4096, (n_ok && a_ok) ? grow[i] + am2x : OOB);
 #pragma unroll
-                for (int sb = 0; sb < NB; ++sb) {
-                    const bool ok = n_ok && b_ok[sb] && (unsigned)(rt[i] * S + bdR[sb]) < (unsigned)p.Lin;
-                    if (!b_one[sb]) wg_bglds16(rsX, bb + sb * WGG_TILE + i * 4096, ok ? xrow[i] + xcol[sb] : OOB);
+                    for (int sb = 0; sb < NB; ++sb) {
+                        const bool ok = n_ok && b_ok[sb] && (unsigned)(rt[i] * S + bdR[sb]) < (unsigned)p.Lin;
+                        wg_bglds16(rsX, bb + sb * WGG_TILE + i * 4096, ok ? xrow[i] + xcol[sb] : OOB);
+                    }
                 }
-                if (abl_noadv) continue;
-                rt[i] += WGG_RK;
-                grow[i] += g_step;
-                xrow[i] += x_step;
-                while (rt[i] >= p.Lout) {
-                    rt[i] -= p.Lout;
-                    ++rb[i];
-                    grow[i] += g_wrap;
-                    xrow[i] += x_wrap;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool n_ok = rb[i] < p.B;
+                    if (NB == 1) wg_bglds16(rsG, ab + i * 4096, (n_ok && a_ok) ? grow[i] + am2x : OOB);
+#pragma unroll
+                    for (int sb = 0; sb < NB; ++sb) {
+                        const bool ok = n_ok && b_ok[sb] && (unsigned)(rt[i] * S + bdR[sb]) < (unsigned)p.Lin;
+                        if (!b_one[sb]) wg_bglds16(rsX, bb + sb * WGG_TILE + i * 4096, ok ? xrow[i] + xcol[sb] : OOB);
+                    }
+                }
+            }
+            if (single_wrap) {  // Lout >= 64: a row crosses at most one item boundary per step
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rt[i] += WGG_RK;
+                    const bool wr = rt[i] >= p.Lout;
+                    rt[i] -= wr ? p.Lout : 0;
+                    rb[i] += wr ? 1 : 0;
+                    grow[i] += g_step + (wr ? g_wrap : 0u);
+                    xrow[i] += x_step + (wr ? x_wrap : 0u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rt[i] += WGG_RK;
+                    grow[i] += g_step;
+                    xrow[i] += x_step;
+                    while (rt[i] >= p.Lout) {
+                        rt[i] -= p.Lout;
+                        ++rb[i];
+                        grow[i] += g_wrap;
+                        xrow[i] += x_wrap;
+                    }
                 }
             }
             return;
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         const int buf = NBUF == 2 ? (st - s_begin) & 1 : 0;
         if (NBUF == 1) {
             if (st > s_begin) __syncthreads();  // everyone is done reading the single buffer
-            if (!(abl_noload && st > s_begin)) issue(0);
+            issue(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -262,11 +292,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
         if (wave_active) {
             const char* Ab = Al + buf * ATILE;
             const char* Bb = Bl + (buf * NB + bsub) * WGG_TILE;
-            bf16x8 a[2], b[2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 if (kk < kk0 || kk >= kk1) continue;
-                if (!(abl_noread && st > s_begin)) {
+                bf16x8 a[2], b[2];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const char* ap = NB == 2 ? Ab + (kk & 1) * 4096 + (kk < 2 ? offA[mi] : offA2[mi]) : Ab + kk * 4096 + offA[mi];
@@ -274,7 +303,6 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) b[ni] = wg_tr_frag(Bb + kk * 4096 + offB[ni], Bb + kk * 4096 + offB[ni] + 1024);
-                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -411,12 +439,7 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
         const char* e = getenv("GA_WGRAD_XCD");
         if (e) xcd = atoi(e);
     }
-    int abl = 0;
-    {
-        const char* e = getenv("GA_WGRAD_ABL");
-        if (e) abl = (atoi(e) & 7) << 8;
-    }
-    const int xcd_wide = (xcd >= 1) | abl, xcd_all = (xcd >= 2) | abl;
+    const int xcd_wide = xcd >= 1, xcd_all = xcd >= 2;
     const long total = base * splits;
     if (total > (1L << 30)) return GA_ERR_ARG;
     const unsigned grid = (unsigned)((total + 7) / 8 * 8);
