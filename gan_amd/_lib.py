@@ -112,6 +112,7 @@ _SIGNATURES = {
     "ga_resunit_bwd": [C.POINTER(ResunitBwdParams), _I, _P],
     "ga_conv_dual_k1": [C.POINTER(DualK1Params), _I, _P],
     "ga_wgrad": [C.POINTER(WgradParams), _I, _I, _P],
+    "ga_wgrad_multi": [_P, _I, _I, _P],
     "ga_wgrad_workspace_elems": [C.POINTER(WgradParams), _I, _I],
     "ga_wn_scale": [_P, _P, _I, _I, _P, _P, _P],
     "ga_pack_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -16,6 +16,7 @@ int ga_conv_coop_wanted(const ConvParams& p);
 int ga_conv_win_impl(const ConvParams& p, hipStream_t s);
 int ga_conv_gemm_variant_impl(const ConvParams& p);
 int ga_set_gemm_lds_budget_impl(int bytes);
+int ga_wgrad_gemm_multi_impl(const WgradParams* items, int n, hipStream_t s);
 int ga_conv_pp_supported(const ConvParams& p);
 int ga_conv_pp_wanted(const ConvParams& p);
 int ga_conv_pp_impl(const ConvParams& p, hipStream_t s);
@@ -171,6 +172,18 @@ int ga_wgrad(const ga_wgrad_params* hp, int dtype, int impl, hipStream_t s) {
         rc = ga_colsum(p.g, dtype, (size_t)p.B * p.Lout, p.M, p.dbias, s);
     }
     return rc;
+}
+
+int ga_wgrad_multi(const ga_wgrad_params* items, int n, int dtype, hipStream_t s) {
+    if (!items || n < 0) return GA_ERR_ARG;
+    if (n == 0) return GA_OK;
+    if (dtype != GA_DTYPE_BF16) return GA_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+        const WgradParams& p = items[i];
+        if (!p.g || !p.x || !p.dw || p.B <= 0 || p.Lin <= 0 || p.Cin <= 0 || p.M <= 0 || p.Lout < 0 || p.J <= 0) return GA_ERR_ARG;
+        if (p.g_stride < 1 || p.LgTot < 1 || p.B > 65535) return GA_ERR_ARG;
+    }
+    return ga_wgrad_gemm_multi_impl(items, n, s);
 }
 
 const char* ga_build_target(void) { return "gfx950"; }

@@ -65,17 +65,9 @@ static __device__ __attribute__((aligned(16))) unsigned int wgg_one_page[4] = {0
 // wraps into the next batch item), so a load needs no 64-bit address arithmetic; rows past the end, columns past M / K and
 // taps outside the item get an offset beyond the buffer and the hardware's range check returns zeros for them.  The bias
 // column's constant-one piece is written to its LDS slot once, up front: the lane that owns the slot never loads into it.
-template <int NBUF, int NB, bool BUF = false>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total, int base, int total, int xcd_order) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    // work item = (output tile bx, reduction slice by), tiles fastest.  Workgroups are dealt to the 8 XCDs round-robin, so in
-    // launch order the k-tiles of one reduction slice -- which read the SAME rows of G and overlapping rows of x -- would land on
-    // eight different L2s and each fetch them from the fabric again (PMC: 4.9 GB per launch for 1.5 GB of operands on D blocks.1);
-    // with xcd_order the ids an XCD receives are consecutive work items instead.  Measured at B = 128: +8-16 % on the 64 x 256
-    // tiles of D blocks.1, +2 % / -4 % / 0 on blocks 2 / 3 / 4 with 128 x 128 tiles: on for the former only (GA_WGRAD_XCD=2: all).
-    int wk = blockIdx.x;
-    if (xcd_order) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
-    if (wk >= total) return;
+template <int NBUF, int NB, bool BUF>
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, char* const smem, const int wk, const int ktiles, const int Ktot,
+                                           const int steps_per_split, const int nsteps_total, const int base) {
     const int bx = wk % base, by = wk / base;
     // NB = 2: the G tile has 64 columns; reduction rows n and n + 32 share one 256-byte LDS row (n + 32 in its second half), so
     // the tile is 8 KiB, the row structure the transposing reads and their swizzle rely on stays, and four workgroups fit a CU
@@ -341,6 +333,42 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(Wgra
     }
 }
 
+template <int NBUF, int NB, bool BUF = false>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 1) void wgrad_gemm_kernel(WgradParams p, int ktiles, int Ktot, int Ntot, int steps_per_split, int nsteps_total, int base, int total, int xcd_order) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // work item = (output tile bx, reduction slice by), tiles fastest.  Workgroups are dealt to the 8 XCDs round-robin, so in
+    // launch order the k-tiles of one reduction slice -- which read the SAME rows of G and overlapping rows of x -- would land on
+    // eight different L2s and each fetch them from the fabric again (PMC: 4.9 GB per launch for 1.5 GB of operands on D blocks.1);
+    // with xcd_order the ids an XCD receives are consecutive work items instead.  Measured at B = 128: +8-16 % on the 64 x 256
+    // tiles of D blocks.1, +2 % / -4 % / 0 on blocks 2 / 3 / 4 with 128 x 128 tiles: on for the former only (GA_WGRAD_XCD=2: all).
+    int wk = blockIdx.x;
+    if (xcd_order) wk = (wk & 7) * (gridDim.x >> 3) + (wk >> 3);
+    if (wk >= total) return;
+    wgrad_tile<NBUF, NB, BUF>(p, smem, wk, ktiles, Ktot, steps_per_split, nsteps_total, base);
+}
+
+// Several weight-gradient problems in ONE launch (the generator's forty 3.7-GFLOP layers: each alone is a 40-50 us launch of
+// ~500 workgroups whose MFMA time is 7 us).  Workgroup ids are dealt problem after problem; the plan of each problem (tiles,
+// slices) is the single-launch plan with a smaller workgroup target.
+#define WGM_MAX 20
+struct WgradMultiArgs {
+    WgradParams p[WGM_MAX];
+    int ktiles[WGM_MAX], sps[WGM_MAX], nsteps[WGM_MAX], base[WGM_MAX];
+    int start[WGM_MAX + 1];  // first workgroup of a problem
+    int n;
+    int xcd_order;           // consecutive work items on one XCD (its L2 then serves the tiles of a reduction slice: they share rows)
+};
+__global__ __launch_bounds__(256, 4) void wgrad_gemm_multi_kernel(const WgradMultiArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    int id = blockIdx.x;
+    if (a.xcd_order) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    if (id >= a.start[a.n]) return;
+    int i = 0;
+    while (i + 1 < a.n && id >= a.start[i + 1]) ++i;
+    const WgradParams& p = a.p[i];
+    wgrad_tile<1, 1, true>(p, smem, id - a.start[i], a.ktiles[i], p.J * p.Cin, a.sps[i], a.nsteps[i], a.base[i]);
+}
+
 int ga_wgrad_gemm_supported(const WgradParams& p) {
     if (p.M % 8 || p.Cin % 8 || p.M < 32 || p.Cin < 8 || p.J < 1) return 0;
     if (p.g_stride != 1 || p.g_phase != 0 || p.tap_step < 0) return 0;
@@ -382,7 +410,7 @@ static bool wgg_wide64(const WgradParams& p) {
     return on && p.M <= 64;
 }
 
-static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles) {
+static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, long& nsteps, int& ktiles, long target = 0) {
     const int Ktot = p.J * p.Cin + (p.dbias ? 8 : 0);  // (+ one 16-byte piece for the bias column)
     const long Ntot = (long)p.B * p.Lout;
     const int mtiles = (p.M + 127) / 128;
@@ -390,15 +418,17 @@ static void wgg_plan(const WgradParams& p, long& base, long& splits, int& sps, l
     ktiles = (Ktot + kw - 1) / kw;
     base = (long)mtiles * ktiles;
     nsteps = (Ntot + WGG_RK - 1) / WGG_RK;
-    splits = (wgg_target_blocks() + base - 1) / base;  // workgroups aimed for
+    if (target <= 0) target = wgg_target_blocks();
+    splits = (target + base - 1) / base;  // workgroups aimed for
     // at least 48 steps (3072 rows) per split: shorter slices are dominated by their prologue and the fp32 atomics of their
     // 64 KiB tile (swept at B = 24) - unless the grid would then leave CUs idle (the generator's few-tile layers), where
     // slices go down to 8 steps to reach about two workgroups per CU
     const long cap48 = (nsteps + 47) / 48, cap8 = (nsteps + 7) / 8;
     if (splits > cap48) splits = cap48;
     if (splits < 1) splits = 1;
-    if (base * splits < 512) {
-        long want = (512 + base - 1) / base;
+    const long floor_blocks = target < 512 ? target : 512;
+    if (base * splits < floor_blocks) {
+        long want = (floor_blocks + base - 1) / base;
         if (want > cap8) want = cap8;
         if (want > splits) splits = want;
     }
@@ -469,6 +499,53 @@ int ga_wgrad_gemm_impl(const WgradParams& p_in, hipStream_t s) {
         long grid = (n4 + 255) / 256;
         if (grid > 4096) grid = 4096;
         wgrad_slab_reduce_kernel<<<(unsigned)grid, 256, 0, s>>>(p.ws, p.dw, n4, (long)p.M * Ktot, (int)splits);
+        GA_CHECK_LAUNCH();
+    }
+    return GA_OK;
+}
+
+// Can ga_wgrad_gemm_multi_impl take this problem?  (The 128 x 128 single-buffer, buffer-staged, atomics form only.)
+int ga_wgrad_gemm_multi_supported(const WgradParams& p) {
+    if (!ga_wgrad_gemm_supported(p) || p.M <= 64 || p.ws || p.Lout <= 0) return 0;
+    if (p.dbias && p.LgTot != p.Lout) return 0;
+    return (long)p.B * p.LgTot * p.M * 2 < (1L << 31) - 64 && (long)p.B * p.Lin * p.Cin * 2 < (1L << 31) - 64;
+}
+
+int ga_wgrad_gemm_multi_impl(const WgradParams* items, int n, hipStream_t s) {
+    for (int i = 0; i < n; ++i)
+        if (!ga_wgrad_gemm_multi_supported(items[i])) return GA_ERR_UNSUPPORTED;
+    for (int c0 = 0; c0 < n; c0 += WGM_MAX) {
+        const int cn = n - c0 < WGM_MAX ? n - c0 : WGM_MAX;
+        WgradMultiArgs a;
+        a.n = cn;
+        // about two launches' worth of workgroups over the whole group, at least one problem's tiles each
+        long tpct = 100;  // workgroup target of a group, in percent of a single launch's (swept 25 .. 400 on the generator's 22 layers)
+        {
+            const char* e = getenv("GA_WGRAD_MULTI_TARGET");
+            if (e && atoi(e) > 0) tpct = atoi(e);
+        }
+        const long target = (tpct * wgg_target_blocks() / 100 + cn - 1) / cn;
+        long at = 0;
+        for (int i = 0; i < cn; ++i) {
+            a.p[i] = items[c0 + i];
+            long base, splits, nsteps;
+            int sps, ktiles;
+            wgg_plan(a.p[i], base, splits, sps, nsteps, ktiles, target);
+            a.ktiles[i] = ktiles;
+            a.sps[i] = sps;
+            a.nsteps[i] = (int)nsteps;
+            a.base[i] = (int)base;
+            a.start[i] = (int)at;
+            at += base * splits;
+            if (at > (1L << 30)) return GA_ERR_ARG;
+        }
+        a.start[cn] = (int)at;
+        for (int i = cn + 1; i <= WGM_MAX; ++i) a.start[i] = (int)at;
+        {
+            const char* e = getenv("GA_WGRAD_MULTI_XCD");
+            a.xcd_order = e ? atoi(e) : 1;
+        }
+        wgrad_gemm_multi_kernel<<<(unsigned)((at + 7) / 8 * 8), 256, 2 * WGG_TILE, s>>>(a);
         GA_CHECK_LAUNCH();
     }
     return GA_OK;

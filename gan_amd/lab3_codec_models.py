@@ -63,7 +63,7 @@ class ResidualFiLMBlock(nn.Module):
 def _conv_train(x, conv: nn.Conv1d, geom: ConvGeom, dtype, post_act=L.ACT_NONE, weight_g=None, weight_v=None):
     v = conv.weight if weight_v is None else weight_v
     wp_f, wp_d, carrier = ops.PackTrainable.apply(v, weight_g, geom, dtype)
-    return ops.ConvTrain.apply(x, wp_f, wp_d, carrier, conv.bias, geom, post_act)
+    return ops.ConvTrain.apply(x, wp_f, wp_d, carrier, conv.bias, geom, post_act, v if weight_g is None else None)
 
 
 class CodecLatentTranslator(nn.Module):

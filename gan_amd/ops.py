@@ -458,7 +458,9 @@ def zeros_f32(n: int, device) -> Tensor:
 # their final place in the optimizer's flat gradient buffer in one launch (ga_wgrad_finish_multi).  p.grad of those
 # parameters stays as it was (None after zero_grad): the flat buffer is what the optimizer and the all-reduce read.
 WGRAD_SINK = True
+WGRAD_DEFER = os.environ.get("GA_WGRAD_DEFER", "1") == "1"  # plain layers' weight gradients in one grouped launch at the end of the pass
 _SINK = None
+LAST_WGRAD_GROUP = None
 
 
 class WeightGradSink:
@@ -469,6 +471,7 @@ class WeightGradSink:
             m = opt._sink_map = {p.data_ptr(): i for i, p in enumerate(opt.params)}
         self.index = m
         self.pending = {}
+        self.deferred = {}    # iv -> (ib | None, v, geom, ga, x): weight gradients not computed yet (ConvTrain.backward, WGRAD_DEFER)
         self.on_offer = None  # dp._OverlapState.learn_pair: told (index of v, index of g | None) of every layer that arrives
 
     def offer(self, v, gparam, norm, geom, gpacked) -> bool:
@@ -477,16 +480,66 @@ class WeightGradSink:
             return False
         iv = self.index.get(v.data_ptr())
         ig = None if gparam is None else self.index.get(gparam.data_ptr())
-        if iv is None or (gparam is not None and ig is None) or iv in self.pending:
+        if iv is None or (gparam is not None and ig is None) or iv in self.pending or iv in self.deferred:
             return False
         self.pending[iv] = (ig, v, gparam, norm, (d0, d1, k), gpacked.contiguous())
         if self.on_offer is not None:
             self.on_offer(iv, ig)
         return True
 
+    def defer(self, v, bias, geom, ga, x) -> bool:
+        """ConvTrain.backward hands over (masked output gradient, layer input) of a plain (no weight norm) layer instead of
+        launching its weight gradient: flush() computes all of them in one grouped launch (ga_wgrad_multi) -- the generator's
+        forty layers are 40-50 us launches one by one, 7 us of MFMA time each.  Not under the overlapped all-reduce (its buckets
+        leave while the pass is still running)."""
+        if self.on_offer is not None or ga.dtype != torch.bfloat16 or geom.kind != "conv" or geom.cin % 8 or geom.cout <= 64:
+            return False
+        d0, d1, k = geom.wdims
+        if geom.fwd_pack != L.PACK_CONV_FWD or d1 * k > L.WFINISH_MAX_ROW:
+            return False
+        iv = self.index.get(v.data_ptr())
+        ib = None if bias is None else self.index.get(bias.data_ptr())
+        if iv is None or (bias is not None and ib is None) or iv in self.pending or iv in self.deferred:
+            return False
+        if self.opt.params[iv].grad is not None or (ib is not None and self.opt.params[ib].grad is not None):
+            return False  # (a gradient from elsewhere is already there: keep to the plain path)
+        self.deferred[iv] = (ib, v, geom, ga, x)
+        return True
+
+    def _run_deferred(self) -> None:
+        todo = list(self.deferred.items())
+        self.deferred = {}
+        if not todo:
+            return
+        opt, lib = self.opt, L.lib()
+        dev = todo[0][1][3].device
+        sizes = [g.cout * g.k * g.cin for _, (_, _, g, _, _) in todo]
+        slab = torch.zeros((sum(sizes),), device=dev, dtype=torch.float32)
+        items = (L.WgradParams * len(todo))()
+        views, off = [], 0
+        for it, n, (iv, (ib, v, g, ga, x)) in zip(items, sizes, todo):
+            dw = slab[off:off + n]
+            off += n
+            views.append(dw)
+            B, lout, _ = ga.shape
+            _fill(it, g=ga.data_ptr(), x=x.data_ptr(), dw=dw.data_ptr(), dbias=None if ib is None else opt.grad_views[ib].data_ptr(),
+                  B=B, Lin=x.shape[1], Cin=g.cin, M=g.cout, Lout=lout, J=g.k, in_stride=g.stride, tap_step=g.dilation,
+                  off0=-g.padding, LgTot=lout, g_stride=1, g_phase=0)
+        rc = lib.ga_wgrad_multi(C.cast(items, C.c_void_p), len(todo), L.DT_BF16, L.stream())
+        global LAST_WGRAD_GROUP
+        LAST_WGRAD_GROUP = (len(todo), rc)  # (layers, status of the grouped call: 0 = one launch per 20, 4 = fell back to one per layer)
+        if rc == 4:  # GA_ERR_UNSUPPORTED: one by one
+            for it in items:
+                L.check(lib.ga_wgrad(C.byref(it), L.DT_BF16, _IMPL, L.stream()), "ga_wgrad")
+        else:
+            L.check(rc, "ga_wgrad_multi")
+        for dw, (iv, (ib, v, g, ga, x)) in zip(views, todo):
+            self.pending[iv] = (None, v, None, None, g.wdims, dw)
+
     def flush(self, only=None) -> None:
         """after opt.gather_grads(): add (p.grad present: it has been copied in) or write (absent) the deferred gradients.
         `only`: finish just these layers (indices of their weights) - the overlapped all-reduce sends bucket by bucket."""
+        self._run_deferred()
         if only is None:
             todo = list(self.pending.items())
             self.pending = {}
@@ -655,10 +708,13 @@ class ConvTrain(torch.autograd.Function):
     wp_f / wp_d come from PackTrainable; the weight gradient is returned in wp_f's packed layout."""
 
     @staticmethod
-    def forward(ctx, x, wp_f, wp_d, carrier, bias, geom: ConvGeom, post_act: int):
+    def forward(ctx, x, wp_f, wp_d, carrier, bias, geom: ConvGeom, post_act: int, vparam=None):
+        """vparam: the layer's weight parameter when it has no weight norm (the generator's convs) -- lets the backward pass
+        leave the weight gradient to the sink's grouped launch."""
         x = x.contiguous()
         y = conv_forward(geom, x, wp_f, bias, post_act=post_act)
         ctx.geom, ctx.post_act = geom, post_act
+        ctx.vparam, ctx.bias_param = vparam, bias
         ctx.save_for_backward(x, wp_d, y if post_act else None)
         ctx.has_bias = bias is not None
         return y
@@ -686,14 +742,17 @@ class ConvTrain(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(geom, ga, wp_d, x.shape[1])
         if ctx.needs_input_grad[3]:
-            if want_b:
+            if (WGRAD_DEFER and _SINK is not None and ctx.vparam is not None
+                    and _SINK.defer(ctx.vparam, ctx.bias_param if want_b else None, geom, ga, x)):
+                pass  # weight (and bias) gradient come out of the sink's grouped launch, straight into the optimizer's flat buffer
+            elif want_b:
                 gw, gb = conv_wgrad(geom, ga, x, want_bias=True)
+                gw = gw.reshape(-1)
             else:
-                gw = conv_wgrad(geom, ga, x)
-            gw = gw.reshape(-1)
+                gw = conv_wgrad(geom, ga, x).reshape(-1)
         elif want_b:
             gb = colsum(ga)
-        return gx, None, None, gw, gb, None, None
+        return gx, None, None, gw, gb, None, None, None
 
 
 class DiscChain(torch.autograd.Function):

@@ -279,6 +279,12 @@ typedef struct ga_wgrad_params {
 /* bf16 kernels: wgrad_gemm_kernel (Cin % 8 == 0); Cin == 1 with a zero-padded x (in_stride 1, tap_step 1, off0 >= 0, J <= 15
  * with dbias, every window in range as for ga_conv): wgrad_cin1_mfma_kernel, which also fills dbias; M == 1: wgrad_m1 kernels. */
 int ga_wgrad(const ga_wgrad_params* h_params, int dtype, int impl, ga_stream_t stream);
+/* n weight-gradient problems (h_items: a HOST array) in one launch per 20 of them, each with the semantics of ga_wgrad (dw and dbias
+ * are added to: the caller zeroes them).  For the generator's many small layers (CodecLatentTranslator, lab3_codec_models.py:50-119:
+ * forty Conv1d(256, 256, 3) over 375 steps), whose loss_g.backward() (lab3_codec_train.py:586) weight gradients are 40-50 us launches
+ * one by one.  bf16, M > 64, ws == NULL, tensors under 2 GiB only: GA_ERR_UNSUPPORTED (nothing launched) if any item does not
+ * qualify -- issue ga_wgrad per item then. */
+int ga_wgrad_multi(const ga_wgrad_params* h_items, int n, int dtype, ga_stream_t stream);
 /* floats of workspace ga_wgrad can use for this problem (0: the kernel it would pick has no slab path) */
 size_t ga_wgrad_workspace_elems(const ga_wgrad_params* h_params, int dtype, int impl);
 

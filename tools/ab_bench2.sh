@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/ab_bench2.sh "VAR=A VAR2=B" "VAR=C" ... [-- rounds]   interleaved bench runs of several environments (fresh process each)
-n=2
+n=${AB_ROUNDS:-2}
 envs=()
 for a in "$@"; do envs+=("$a"); done
 for i in $(seq $n); do
