@@ -54,6 +54,10 @@ def _rule(key: str, shape) -> tuple:
         return 1.0, 0.0  # direction only; row norm divides out
     if "lstm" in key:
         return (1.0 / np.sqrt(512.0)), 0.0
+    if leaf == "running_var":  # BatchNorm buffer, strictly positive
+        return 0.25, 1.0
+    if nd == 4:  # Conv2d [Cout, Cin, kh, kw] / ConvTranspose2d [Cin, Cout, kh, kw] weight (the mel track)
+        return float(np.sqrt(3.0 / (shape[1] * shape[2] * shape[3]))), 0.0
     if nd == 3:  # plain Conv1d weight [Cout, Cin, k]
         fan_in = shape[1] * shape[2]
         return float(np.sqrt(3.0 / fan_in)), 0.0
