@@ -1,0 +1,87 @@
+"""2-D convolutions of the mel track on the library's 1-D implicit-GEMM kernels (channels-last activations [B, H, W, C]).
+
+    y[b, oh, ow, m] = sum_{i, j, c} x[b, s*oh + i - p, s*ow + j - p, c] * w[m, c, i, j]
+
+With channels last, the (j, c) window of one kernel row i is CONTIGUOUS along W -- exactly the im2col row the gathered-GEMM kernel
+reads through its per-lane addresses -- so only the kernel ROWS need gathering: xr[b, oh, w, i*C + c] = x[b, s*oh + i - p, w, c] (one
+concatenation of kh strided row slices, kh / s times the input; zero rows for the padding).  What is left is a 1-D convolution along W
+over B*OH items with kh*C input channels and kw taps: `ops.ConvTrain` (ga_conv forward and data gradient, ga_wgrad, bias /
+LeakyReLU in the epilogue).  Autograd carries the gradient through the row gather and the weight re-arrangement (views and copies).
+
+Reference layers this serves: nn.Conv2d / nn.ConvTranspose2d in /root/reference/lab 3/src/lab3_models.py:22-27,88,95,101,114,156-164.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .ops import ConvGeom
+
+
+def to_nhwc(h_nchw: torch.Tensor) -> torch.Tensor:
+    """[B, C, H, W] (any strides) -> contiguous [B, H, W, C]; free when the tensor already is channels-last."""
+    return h_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw_view(y_nhwc: torch.Tensor) -> torch.Tensor:
+    """contiguous [B, H, W, C] -> the [B, C, H, W] view of the same memory (channels-last strides)."""
+    return y_nhwc.permute(0, 3, 1, 2)
+
+
+def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int,
+                post_act: int = L.ACT_NONE) -> torch.Tensor:
+    """x [B, H, W, C] (fp32 or bf16, contiguous), weight [M, C, kh, kw] and bias [M] (fp32 parameters) -> [B, OH, OW, M] in x's dtype."""
+    L.require_cuda(x, weight)
+    B, H, W, C = x.shape
+    M, Cw, kh, kw = weight.shape
+    if Cw != C:
+        raise ValueError(f"weight expects {Cw} input channels, got {C}")
+    s, p = int(stride), int(padding)
+    OH = (H + 2 * p - kh) // s + 1
+    if OH < 1 or (W + 2 * p - kw) // s + 1 < 1:
+        raise ValueError("convolution window larger than the padded input")
+    xp = F.pad(x, (0, 0, 0, 0, p, p)) if p else x  # zero rows above and below
+    last = s * (OH - 1) + 1
+    rows = [xp[:, i:i + last:s] for i in range(kh)]
+    kc = kh * C
+    kc8 = (kc + 7) // 8 * 8  # the GEMM kernels stage 16-byte (8-channel) pieces
+    if kc8 != kc:
+        rows.append(x.new_zeros(B, OH, W, kc8 - kc))
+    xr = torch.cat(rows, dim=-1) if len(rows) > 1 else rows[0].contiguous()
+    w1 = weight.permute(0, 2, 1, 3).reshape(M, kc, kw)  # [m, (i, c), j]
+    if kc8 != kc:
+        w1 = F.pad(w1, (0, 0, 0, kc8 - kc))
+    geom = ConvGeom("conv", kc8, M, kw, s, p, 1)
+    wp_f, wp_d, carrier = ops.PackTrainable.apply(w1.contiguous(), None, geom, x.dtype)
+    y = ops.ConvTrain.apply(xr.view(B * OH, W, kc8), wp_f, wp_d, carrier, bias, geom, post_act, None)
+    return y.view(B, OH, geom.out_len(W), M)
+
+
+# ConvTranspose2d(kernel 4, stride 2, padding 1): y[2t + phi] = sum over the two kernel taps of phase phi.  Along one axis
+#   phi = 0: x[t-1] * w[3] + x[t] * w[1]        phi = 1: x[t] * w[2] + x[t+1] * w[0]
+# i.e. a 3-tap convolution (offsets -1, 0, +1) whose taps are a subset of the 4-tap kernel: {tap: kernel index} per phase.
+_TAPS = ({0: 3, 1: 1}, {1: 2, 2: 0})
+
+
+def conv_transpose2d_k4s2p1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], post_act: int = L.ACT_NONE) -> torch.Tensor:
+    """x [B, H, W, C], weight [C, M, 4, 4] (ConvTranspose2d layout), bias [M] -> [B, 2H, 2W, M].  The four output phases are four
+    2 x 2 convolutions over x; they run as ONE 3 x 3 implicit GEMM onto 4M channels (m, phi_h, phi_w) -- 4 of the 9 taps of each
+    phase are structural zeros: 2.25x the multiply-adds of the four separate GEMMs, on layers of 0.1-0.2 GMAC per sample -- and
+    a pixel shuffle puts the phases in place."""
+    C, M = weight.shape[0], weight.shape[1]
+    if tuple(weight.shape[2:]) != (4, 4):
+        raise ValueError("kernel 4 x 4 expected")
+    w3 = weight.new_zeros(M, 2, 2, C, 3, 3)
+    for ph in (0, 1):
+        for a, ih in _TAPS[ph].items():
+            for pw in (0, 1):
+                for b, iw in _TAPS[pw].items():
+                    w3[:, ph, pw, :, a, b] = weight[:, :, ih, iw].t()
+    b4 = None if bias is None else bias.repeat_interleave(4)
+    y = conv2d_nhwc(x, w3.view(4 * M, C, 3, 3), b4, 1, 1, post_act)  # [B, H, W, (m, ph, pw)]
+    B, H, W, _ = y.shape
+    return y.view(B, H, W, M, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, M)

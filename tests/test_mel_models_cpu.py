@@ -1,0 +1,58 @@
+"""CPU: the mel-track product modules (gan_amd/lab3_models.py, lab3_train.py) expose the reference's state-dict keys, shapes and
+constructor errors, and refuse to run without a GPU (no CPU fallback)."""
+import pytest
+import torch
+
+from gan_amd import lab3_models as PM
+from gan_amd import lab3_train as PT
+from oracle import mel_oracle as M
+from tests.mel_shapes import decoder_state_shapes, wrapper_state_shapes
+
+
+@pytest.mark.parametrize("kw", [{}, dict(upsample="pixelshuffle", norm="batch"), dict(upsample="nearest"), dict(mrf=True, base_channels=64),
+                                dict(zc_dim=16, cond_dim=8, n_mels=16, n_frames=32, base_channels=32)])
+def test_decoder_state_dict_matches_the_reference_layout(kw):
+    G = PM.ReconstructionDecoder(**kw)
+    want = decoder_state_shapes(M.DecoderCfg(**kw))
+    got = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    assert list(got) == list(want), (list(got), list(want))  # same keys in the same (registration) order
+    assert got == want
+
+
+@pytest.mark.parametrize("mk,spec", [
+    (lambda: PM.MelDiscriminator(cond_dim=0), dict(kind="single", base=64, cond_dim=0)),
+    (lambda: PM.MelDiscriminator(base_channels=16, cond_dim=160), dict(kind="single", base=16, cond_dim=160)),
+    (lambda: PM.MultiScaleMelDiscriminator(cond_dim=160, base_channels=16), dict(kind="multiscale", base=16, cond_dim=160)),
+    (lambda: PM.SubBandMelDiscriminator(cond_dim=160, base_channels=16), dict(kind="subband", base=16, cond_dim=160)),
+    (lambda: PM.MultiPeriodMelDiscriminator(cond_dim=160, base_channels=16), dict(kind="multiperiod", base=16, cond_dim=160)),
+    (lambda: PM.HybridMelDiscriminator(cond_dim=160), dict(kind="hybrid", base=64, cond_dim=160))])
+def test_discriminator_state_dicts_match_the_reference_layout(mk, spec):
+    got = {k: tuple(v.shape) for k, v in mk().state_dict().items()}
+    want = wrapper_state_shapes(**spec)
+    assert set(got) == set(want) and got == {k: want[k] for k in got}
+
+
+def test_constructor_errors_and_unsupported_options():
+    with pytest.raises(ValueError):
+        PM.ReconstructionDecoder(n_mels=90)
+    with pytest.raises(ValueError):
+        PM.ReconstructionDecoder(upsample="bilinear")
+    with pytest.raises(ValueError):
+        PM.ReconstructionDecoder(norm="layer")
+    with pytest.raises(ValueError):
+        PM.MultiScaleMelDiscriminator(num_scales=0)
+    with pytest.raises(NotImplementedError):
+        PM.MelDiscriminator(spectral_norm=True)
+    with pytest.raises(ValueError):
+        PT._gan_d_loss("wgan", torch.zeros(2), torch.zeros(2), 1.0, 0.0)
+    cfg = PT.StageTrainConfig(stage_name="stage1", epochs=1)
+    assert cfg.gan_loss == "bce" and cfg.betas == (0.5, 0.999) and cfg.weights.recon_l1 == 8.0 and cfg.mrstft_resolutions[0] == (64, 16, 64)
+
+
+def test_no_cpu_fallback():
+    G = PM.ReconstructionDecoder(zc_dim=16, cond_dim=8, n_mels=16, n_frames=32, base_channels=32)
+    with pytest.raises(Exception):
+        G(torch.zeros(1, 16), torch.zeros(1, 8))
+    D = PM.MelDiscriminator(base_channels=16)
+    with pytest.raises(Exception):
+        D(torch.zeros(1, 32, 64))
