@@ -1,22 +1,26 @@
-"""Mel-track stage-1 training of the reference (lab 3/src/lab3_train.py) on the HIP-backed models of gan_amd/lab3_models.py.
+"""Mel-track training of the reference (lab 3/src/lab3_train.py) on the HIP-backed models of gan_amd/lab3_models.py.
 
-SURVEY.md section 8(f) next-4, first slice: `TrainWeights` (:31-56), `StageTrainConfig` (:58-126), `_gan_d_loss` / `_gan_g_loss`
-(:297-326) and `train_stage1` (:342-483) with the reference's names, arguments and history rows; one pass of its loop body is
-`mel_stage1_iteration`.  Adam (torch.optim.Adam at :357-358) and the optional gradient clipping (:409-410, :447-448) run as the fused
-clip + AdamW kernel with weight decay 0.  Not in this slice: `train_stage2` (:486-1088, the 23-term stage) and R1 (:329-339,
-:402-404: a double backward through BatchNorm) -- asking for either raises.
+SURVEY.md section 8(f) next-4: `TrainWeights` (:31-56), `StageTrainConfig` (:58-126), the bank builders and target samplers
+(:129-204), `_gan_d_loss` / `_gan_g_loss` (:297-326), `train_stage1` (:342-483) and `train_stage2` (:486-1088) with the reference's
+names, arguments, history rows and checkpoint keys; one pass of a loop body is `mel_stage1_iteration` / `Stage2Runner.iteration`.
+Adam (torch.optim.Adam at :357-358, :538-540) and the optional gradient clipping run as the fused clip + AdamW kernel with weight
+decay 0; the optimizer of the caller's thawed encoder parameters (:532-536) stays torch.optim.Adam, on the caller's own module.
+Not implemented: R1 (:329-339, a double backward through BatchNorm) -- r1_gamma > 0 raises.
 """
 from __future__ import annotations
 
+import json
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import lab3_losses as LL
 from .lab3_losses import multi_resolution_stft_loss
-from .lab3_models import bce_logits
+from .lab3_models import StyleCritic, bce_logits
 from .optim import FusedAdamW
 
 MEL_DB_MIN, MEL_DB_MAX = -80.0, 0.0  # lab3_bridge.py (denormalize_log_mel, :135-139)
@@ -52,8 +56,7 @@ class TrainWeights:
 
 @dataclass
 class StageTrainConfig:
-    """The fields of the reference's StageTrainConfig (lab3_train.py:58-126) that stage 1 reads, with its defaults; stage-2-only
-    controls are accepted through `extra` so that a reference call site's keyword arguments do not fail."""
+    """reference lab3_train.py:58-126, field for field with its defaults (`extra` is this build's: test switches only)."""
     stage_name: str
     epochs: int
     lr_g: float = 2e-4
@@ -63,16 +66,132 @@ class StageTrainConfig:
     gan_loss: str = "bce"
     disc_use_content_cond: bool = False
     weights: TrainWeights = field(default_factory=TrainWeights)
+    # stage-2 controls (stage 1 ignores them)
+    content_weight_start: Optional[float] = None
+    content_weight_end: Optional[float] = None
+    style_label_smoothing: float = 0.0
+    style_only_warmup_epochs: int = 0
+    g_lr_warmup_epochs: int = 0
+    g_lr_start_mult: float = 1.0
+    cond_noise_std: float = 0.0
+    style_jitter_std: float = 0.0
+    cond_mode: str = "mix"  # centroid | exemplar | mix
+    cond_alpha_start: float = 0.8
+    cond_alpha_end: float = 0.4
+    cond_exemplar_noise_std: float = 0.03
+    target_balance: bool = True
+    style_hinge_target_conf: float = 0.85
+    adaptive_content_weight: bool = False
+    adaptive_content_low: float = 0.05
+    adaptive_content_high: float = 0.5
+    adaptive_conf_low: float = 0.5
+    adaptive_conf_high: float = 0.8
+    style_class_balance: bool = False
+    style_critic_lr: float = 2e-4
+    contrastive_temp: float = 0.10
+    diversity_margin: float = 0.90
+    diversity_max_pairs: int = 64
+    style_lowpass_keep_bins: int = 80
+    style_lowpass_cutoff_hz: Optional[float] = None
+    style_mid_low_bin: int = 8
+    style_mid_high_bin: int = 56
+    lowmid_split_bin: int = 80
+    lowmid_gain: float = 5.0
+    high_gain: float = 0.5
+    spectral_tilt_max_ratio: float = 0.7
+    zcr_proxy_target_max: float = 0.18
+    hf_top_frac: float = 0.20
+    hf_max_ratio_multiplier: float = 1.20
+    highpass_cut_bin: int = 12
+    highpass_gain: float = 2.0
+    mel_diversity_margin: float = 0.85
+    mel_diversity_max_pairs: int = 64
     d_real_label: float = 1.0
     d_fake_label: float = 0.0
     g_real_label: float = 1.0
     r1_gamma: float = 0.0
     r1_interval: int = 16
+    d_loss_floor_for_step: float = 0.0
     d_step_period: int = 1
     g_grad_clip_norm: float = 0.0
     d_grad_clip_norm: float = 0.0
+    style_thaw_last_epochs: int = 0
+    style_thaw_lr: float = 1e-6
+    style_thaw_scope: str = "style_head"
+    batch_infonce_temp: float = 0.15
     mrstft_resolutions: Tuple[Tuple[int, int, int], ...] = ((64, 16, 64), (128, 32, 128), (256, 64, 256))
     extra: Dict[str, object] = field(default_factory=dict)
+
+
+def load_target_centroids(target_centroids_json: Path) -> Dict[str, np.ndarray]:
+    """reference lab3_train.py:129-146: {genre: unit vector} from a JSON of {"vector" | "vector160": [...]} records."""
+    path = Path(target_centroids_json)
+    if not path.exists():
+        raise FileNotFoundError(f"Target centroid file not found: {path}")
+    records = json.loads(path.read_text(encoding="utf-8"))
+    out: Dict[str, np.ndarray] = {}
+    for genre, rec in records.items():
+        key = "vector" if "vector" in rec else "vector160" if "vector160" in rec else None
+        if key is None:
+            raise ValueError(f"Missing vector field for genre {genre}")
+        v = np.asarray(rec[key], dtype=np.float32)
+        out[str(genre)] = v / (np.linalg.norm(v) + 1e-8)
+    return out
+
+
+def build_condition_bank(genre_to_idx: Dict[str, int], centroid_map: Dict[str, np.ndarray]) -> torch.Tensor:
+    """reference :149-157: [n_genres, dim], row idx = that genre's centroid."""
+    missing = [g for g in genre_to_idx if g not in centroid_map]
+    if missing:
+        raise ValueError(f"Centroid map missing genres: {missing}")
+    bank = np.zeros((len(genre_to_idx), len(next(iter(centroid_map.values())))), dtype=np.float32)
+    for genre, idx in genre_to_idx.items():
+        bank[int(idx)] = centroid_map[genre]
+    return torch.from_numpy(bank)
+
+
+def build_style_centroid_bank(z_style: np.ndarray, genre_idx: np.ndarray, n_genres: int) -> torch.Tensor:
+    """reference :160-168: per-genre mean of z_style, L2-normalised; zero rows for absent genres."""
+    bank = np.zeros((int(n_genres), z_style.shape[1]), dtype=np.float32)
+    for g in range(int(n_genres)):
+        rows = z_style[genre_idx == g]
+        if len(rows):
+            v = rows.mean(axis=0).astype(np.float32)
+            bank[g] = v / (np.linalg.norm(v) + 1e-8)
+    return torch.from_numpy(bank)
+
+
+def build_style_exemplar_bank(z_style: np.ndarray, genre_idx: np.ndarray, n_genres: int) -> Dict[int, torch.Tensor]:
+    """reference :171-183: {genre: its L2-normalised z_style rows} for the genres that occur."""
+    bank: Dict[int, torch.Tensor] = {}
+    for g in range(int(n_genres)):
+        rows = z_style[genre_idx == g].astype(np.float32)
+        if len(rows):
+            bank[g] = torch.from_numpy(rows / (np.linalg.norm(rows, axis=1, keepdims=True) + 1e-8))
+    return bank
+
+
+def _bump_clashes(tgt: torch.Tensor, source_idx: torch.Tensor, n_genres: int) -> torch.Tensor:
+    return torch.where(tgt == source_idx, (tgt + 1) % int(n_genres), tgt)
+
+
+def _sample_shift_targets(source_idx: torch.Tensor, n_genres: int) -> torch.Tensor:
+    """reference :186-193: uniform targets, moved one genre on where they hit the source."""
+    tgt = torch.randint(low=0, high=int(n_genres), size=(int(source_idx.shape[0]),), device=source_idx.device)
+    return _bump_clashes(tgt, source_idx, n_genres)
+
+
+def _sample_shift_targets_balanced(source_idx: torch.Tensor, n_genres: int, offset: int = 0) -> torch.Tensor:
+    """reference :196-204: round-robin targets starting at `offset`, same clash rule."""
+    tgt = (torch.arange(int(source_idx.shape[0]), device=source_idx.device, dtype=torch.long) + int(offset)) % int(n_genres)
+    return _bump_clashes(tgt, source_idx, n_genres)
+
+
+def _linear_weight(start: float, end: float, epoch_idx: int, total_epochs: int) -> float:
+    """reference :285-289."""
+    if total_epochs <= 1:
+        return float(end)
+    return float(start + (end - start) * (float(epoch_idx) / float(total_epochs - 1)))
 
 
 def _gan_d_loss(gan_loss: str, logits_real: torch.Tensor, logits_fake: torch.Tensor, d_real_label: float, d_fake_label: float) -> torch.Tensor:
@@ -165,26 +284,33 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
     return out
 
 
-def _save_stage_checkpoint(path: Path, epoch: int, generator, discriminator, opt_g, opt_d, meta: Optional[Dict] = None) -> None:
+def _save_stage_checkpoint(path: Path, epoch: int, generator, discriminator, opt_g, opt_d, meta: Optional[Dict] = None, style_critic=None,
+                           opt_sc=None, frozen_encoder_model=None, opt_style_thaw=None) -> None:
     """reference lab3_train.py:207-237: the same dictionary keys (optimizer states in torch.optim.Adam's layout)."""
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    torch.save({"epoch": int(epoch), "generator": generator.state_dict(), "discriminator": discriminator.state_dict(),
-                "opt_g": opt_g.state_dict(), "opt_d": opt_d.state_dict(), "meta": meta or {}}, path)
+    payload = {"epoch": int(epoch), "generator": generator.state_dict(), "discriminator": discriminator.state_dict(),
+               "opt_g": opt_g.state_dict(), "opt_d": opt_d.state_dict(), "meta": meta or {}}
+    for key, obj in (("style_critic", style_critic), ("opt_sc", opt_sc), ("frozen_encoder_model", frozen_encoder_model),
+                     ("opt_style_thaw", opt_style_thaw)):
+        if obj is not None:
+            payload[key] = obj.state_dict()
+    torch.save(payload, path)
 
 
-def _load_stage_checkpoint(path: Path, generator, discriminator, opt_g, opt_d) -> int:
-    """reference lab3_train.py:240-276: epoch to resume from (0 when there is no checkpoint)."""
+def _load_stage_checkpoint(path: Path, generator, discriminator, opt_g, opt_d, style_critic=None, opt_sc=None, frozen_encoder_model=None,
+                           opt_style_thaw=None) -> int:
+    """reference lab3_train.py:240-276: epoch to resume from (0 when there is no checkpoint).  Read with weights_only=True."""
     path = Path(path)
     if not path.exists():
         return 0
     ckpt = torch.load(path, map_location="cpu", weights_only=True)
     generator.load_state_dict(ckpt["generator"], strict=True)
     discriminator.load_state_dict(ckpt["discriminator"], strict=True)
-    if "opt_g" in ckpt:
-        opt_g.load_state_dict(ckpt["opt_g"])
-    if "opt_d" in ckpt:
-        opt_d.load_state_dict(ckpt["opt_d"])
+    for key, obj in (("opt_g", opt_g), ("opt_d", opt_d), ("style_critic", style_critic), ("opt_sc", opt_sc),
+                     ("frozen_encoder_model", frozen_encoder_model), ("opt_style_thaw", opt_style_thaw)):
+        if obj is not None and key in ckpt:
+            obj.load_state_dict(ckpt[key])
     return int(ckpt.get("epoch", 0))
 
 
@@ -223,4 +349,303 @@ def train_stage1(generator, discriminator, frozen_encoder, train_loader, cond_ba
         history.append(ep)
         _save_stage_checkpoint(checkpoint_path, int(epoch + 1), generator, discriminator, opt_g, opt_d, meta={"stage": "stage1"})
         print(f"[stage1] epoch={epoch + 1} loss_g={ep['loss_g']:.4f} loss_d={ep['loss_d']:.4f}")
+    return history
+
+
+STAGE2_KEYS = ("loss_g", "loss_d", "loss_r1", "loss_sc", "loss_adv", "loss_l1", "loss_continuity", "loss_mrstft", "loss_content",
+               "loss_style_ce", "loss_style_mid", "loss_pfm_style", "loss_contrastive", "loss_batch_infonce_diversity", "loss_style_hinge",
+               "loss_lowmid_recon", "loss_flatness", "loss_timbre_balance", "loss_spectral_tilt", "loss_zcr_proxy", "loss_hf_muzzle",
+               "loss_highpass_anchor", "loss_feature_match", "loss_perceptual", "loss_diversity", "loss_mel_diversity",
+               "loss_target_profile", "content_weight", "lr_g", "style_conf", "style_thaw_active", "cond_alpha")  # history row, :690-723
+
+
+def _same_target_pair_hinge(feat: torch.Tensor, tgt_idx: torch.Tensor, margin: float, max_pairs: int) -> torch.Tensor:
+    """`_diversity_loss` / `_mel_diversity_loss` (reference :580-605, :634-659): within every target genre, neighbours of a random
+    permutation form pairs; mean over genres of mean relu(cos - margin), spending at most max_pairs pairs."""
+    zero = torch.zeros((), device=feat.device)
+    if feat.shape[0] < 2:
+        return zero
+    f = F.normalize(feat, dim=-1)
+    budget, terms = int(max_pairs), []
+    for g in torch.unique(tgt_idx):
+        ids = torch.where(tgt_idx == g)[0]
+        if ids.numel() < 2:
+            continue
+        order = ids[torch.randperm(ids.numel(), device=feat.device)]
+        a, b = order[:-1], order[1:]
+        if budget > 0 and a.numel() > budget:
+            a, b = a[:budget], b[:budget]
+        terms.append(F.relu((f[a] * f[b]).sum(dim=-1) - float(margin)).mean())
+        budget -= int(a.numel())
+        if budget <= 0:
+            break
+    return torch.stack(terms).mean() if terms else zero
+
+
+def _within_genre_infonce(z_fake: torch.Tensor, tgt_idx: torch.Tensor, temp: float) -> torch.Tensor:
+    """`_batch_infonce_diversity_loss` (reference :607-632): per target genre, cross-entropy of z z_detached^T / temp against the
+    diagonal -- the other samples of the genre are the negatives."""
+    zero = torch.zeros((), device=z_fake.device)
+    if z_fake.shape[0] < 2:
+        return zero
+    z = F.normalize(z_fake, dim=-1)
+    terms = []
+    for g in torch.unique(tgt_idx):
+        ids = torch.where(tgt_idx == g)[0]
+        if ids.numel() < 2:
+            continue
+        zg = z[ids]
+        terms.append(F.cross_entropy(zg @ zg.detach().t() / float(temp), torch.arange(zg.shape[0], device=z.device)))
+    return torch.stack(terms).mean() if terms else zero
+
+
+def _style_thaw_parameters(encoder_model, scope: str) -> list:
+    """reference :515-529."""
+    key = str(scope).strip().lower()
+    parts = {"style_head": ("style_head",), "shared_style": ("shared", "style_head"), "full_style_path": ("backbone", "shared", "style_head")}
+    if key not in parts:
+        raise ValueError(f"Unsupported style_thaw_scope: {scope}")
+    return [p for name in parts[key] for p in getattr(encoder_model, name).parameters()]
+
+
+def _stage2_condition(stage_cfg: StageTrainConfig, cond_bank, exemplars: Dict[int, torch.Tensor], tgt_idx, epoch: int):
+    """(cond [B, cond_dim], cond_alpha) of reference :739-791: target centroid, a drawn exemplar of the target genre written over its
+    leading dimensions, or their scheduled mix; then conditioning noise / style jitter."""
+    centroid = cond_bank[tgt_idx]
+    mode = str(stage_cfg.cond_mode).strip().lower()
+    exemplar = centroid
+    if mode in {"exemplar", "mix"} and exemplars:
+        rows = []
+        for j, tg in enumerate(tgt_idx.tolist()):
+            pool = exemplars.get(int(tg))
+            if pool is None or pool.shape[0] == 0:
+                rows.append(centroid[j])
+                continue
+            v = pool[int(torch.randint(0, int(pool.shape[0]), (1,), device=tgt_idx.device).item())]
+            if float(stage_cfg.cond_exemplar_noise_std) > 0.0:
+                v = F.normalize(v + torch.randn_like(v) * float(stage_cfg.cond_exemplar_noise_std), dim=-1)
+            rows.append(v)
+        raw = torch.stack(rows, dim=0)
+        k = min(int(centroid.shape[1]), int(raw.shape[1]))  # a longer cond keeps the centroid's tail
+        exemplar = F.normalize(torch.cat([raw[:, :k], centroid[:, k:]], dim=1), dim=-1)
+    if mode == "exemplar":
+        cond, alpha = exemplar, 0.0
+    elif mode == "mix":
+        alpha = _linear_weight(float(stage_cfg.cond_alpha_start), float(stage_cfg.cond_alpha_end), int(epoch), int(stage_cfg.epochs))
+        cond = F.normalize(float(alpha) * centroid + (1.0 - float(alpha)) * exemplar, dim=-1)
+    else:
+        cond, alpha = centroid, 1.0
+    noise = [torch.randn_like(cond) * float(std) for std in (stage_cfg.cond_noise_std, stage_cfg.style_jitter_std) if float(std) > 0.0]
+    if noise:
+        cond = F.normalize(cond + sum(noise), dim=-1)
+    return cond, float(alpha)
+
+
+def _target_reference_rows(gidx: torch.Tensor, tgt_idx: torch.Tensor) -> torch.Tensor:
+    """reference :891-905: for every sample, a batch row whose genre is the sample's target (any row when there is none)."""
+    src, n = gidx.tolist(), int(gidx.shape[0])
+    by_genre: Dict[int, List[int]] = {}
+    for j, g in enumerate(src):
+        by_genre.setdefault(int(g), []).append(j)
+    rows = []
+    for tg in tgt_idx.tolist():
+        cands = by_genre.get(int(tg), [])
+        pick = int(torch.randint(0, len(cands) if cands else n, (1,), device=gidx.device).item())
+        rows.append(cands[pick] if cands else pick)
+    return torch.tensor(rows, device=gidx.device, dtype=torch.long)
+
+
+def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_bank: torch.Tensor, style_proto_bank: torch.Tensor,
+                 style_exemplar_bank: Optional[Dict[int, torch.Tensor]], target_profile_bank: Optional[torch.Tensor], device,
+                 stage_cfg: StageTrainConfig, checkpoint_path: Path, resume: bool = False) -> List[Dict]:
+    """reference lab3_train.py:486-1088: same arguments, same history rows, same checkpoint keys.  The generator and discriminator
+    passes run on the HIP kernels; the frozen encoder is the caller's module; the 20-odd scalar penalties are device tensor expressions
+    (lab3_losses.py).  Host reads per iteration: the D loss when `d_loss_floor_for_step` is set and the two confidences when
+    `adaptive_content_weight` is -- both are data-dependent control flow in the reference; the history sums stay on the device."""
+    if float(stage_cfg.r1_gamma) > 0.0:
+        raise NotImplementedError("R1 on the mel discriminator (a double backward through BatchNorm) is not implemented")
+    generator.train()
+    discriminator.train()
+    cond_bank = cond_bank.to(device)
+    protos = F.normalize(style_proto_bank.to(device), dim=-1)
+    exemplars = {int(g): F.normalize(t.to(device).float(), dim=-1) for g, t in (style_exemplar_bank or {}).items()}
+    if target_profile_bank is not None:
+        target_profile_bank = target_profile_bank.to(device)
+    n_genres = int(cond_bank.shape[0])
+    style_critic = StyleCritic(in_dim=int(protos.shape[1]), n_classes=n_genres).to(device)
+    style_critic.train()
+    thaw_epochs = max(0, int(stage_cfg.style_thaw_last_epochs))
+    thaw_params = _style_thaw_parameters(frozen_encoder.model, stage_cfg.style_thaw_scope)
+    for p in thaw_params:
+        p.requires_grad = False
+    opt_thaw = torch.optim.Adam(thaw_params, lr=float(stage_cfg.style_thaw_lr), betas=stage_cfg.betas) if thaw_params else None
+    opt_g = FusedAdamW(generator.parameters(), lr=stage_cfg.lr_g, betas=stage_cfg.betas, weight_decay=0.0)
+    opt_d = FusedAdamW(discriminator.parameters(), lr=stage_cfg.lr_d, betas=stage_cfg.betas, weight_decay=0.0)
+    opt_sc = FusedAdamW(style_critic.parameters(), lr=float(stage_cfg.style_critic_lr), betas=stage_cfg.betas, weight_decay=0.0)
+    class_w = torch.ones((n_genres,), device=device, dtype=torch.float32)
+    labels = getattr(getattr(train_loader, "dataset", None), "genre_idx", None)
+    if bool(stage_cfg.style_class_balance) and labels is not None:  # inverse frequency, mean 1 (:542-549)
+        inv = 1.0 / np.maximum(np.bincount(np.asarray(labels, dtype=np.int64), minlength=n_genres).astype(np.float32), 1.0)
+        class_w = torch.from_numpy(inv / max(float(inv.mean()), 1e-8)).to(device=device, dtype=torch.float32)
+    start_epoch = _load_stage_checkpoint(checkpoint_path, generator, discriminator, opt_g, opt_d, style_critic=style_critic, opt_sc=opt_sc,
+                                         frozen_encoder_model=frozen_encoder.model, opt_style_thaw=opt_thaw) if resume else 0
+    w = stage_cfg.weights
+    smoothing = float(stage_cfg.style_label_smoothing)
+    d_params = list(discriminator.parameters())
+    history: List[Dict] = []
+    step_idx = 0
+    lp_bins: Optional[int] = None
+    for epoch in range(start_epoch, int(stage_cfg.epochs)):
+        thaw_active = bool(thaw_epochs > 0 and epoch >= int(stage_cfg.epochs) - thaw_epochs)
+        for p in thaw_params:
+            p.requires_grad = thaw_active
+        warm = max(0, int(stage_cfg.g_lr_warmup_epochs))
+        cur_lr_g = float(stage_cfg.lr_g)
+        if warm > 0 and epoch < warm:  # linear from g_lr_start_mult to 1 over the warm-up epochs (:668-674)
+            m0 = float(stage_cfg.g_lr_start_mult)
+            cur_lr_g *= m0 + (1.0 - m0) * (float(epoch + 1) / float(warm))
+        opt_g.lr = cur_lr_g
+        style_only = max(0, int(stage_cfg.style_only_warmup_epochs))
+        if epoch < style_only:
+            content_w = 0.0
+        elif stage_cfg.content_weight_start is not None and stage_cfg.content_weight_end is not None:
+            content_w = _linear_weight(float(stage_cfg.content_weight_start), float(stage_cfg.content_weight_end), int(epoch) - style_only,
+                                       max(1, int(stage_cfg.epochs) - style_only))
+        else:
+            content_w = float(w.content)
+        sums = torch.zeros(len(STAGE2_KEYS), device=device, dtype=torch.float64)
+        nb = taken = skipped = 0
+        ema_conf: Optional[float] = None
+        for bidx, batch in enumerate(train_loader):
+            if stage_cfg.max_batches_per_epoch is not None and bidx >= int(stage_cfg.max_batches_per_epoch):
+                break
+            real = batch["mel_norm"].to(device).float()
+            zc = batch["z_content"].to(device).float()
+            gidx = batch["genre_idx"].to(device).long()
+            tgt_idx = (_sample_shift_targets_balanced(gidx, n_genres, offset=step_idx) if bool(stage_cfg.target_balance)
+                       else _sample_shift_targets(gidx, n_genres))
+            cond, cond_alpha = _stage2_condition(stage_cfg, cond_bank, exemplars, tgt_idx, epoch)
+            cond_d = torch.cat([cond, zc], dim=1) if bool(stage_cfg.disc_use_content_cond) else cond
+            do_d_step = (step_idx % int(max(1, stage_cfg.d_step_period))) == 0
+            real_db = denormalize_log_mel(real)
+            if lp_bins is None:
+                cut = stage_cfg.style_lowpass_cutoff_hz
+                lp_bins = (LL.estimate_lowpass_keep_bins(int(real_db.shape[1]), int(frozen_encoder.cfg.sample_rate), float(cut))
+                           if cut is not None and float(cut) > 0.0 else int(stage_cfg.style_lowpass_keep_bins))
+            real_db_lp = LL.lowpass_mel_db(real_db, keep_bins=lp_bins)
+            # style critic on the real latents (:806-814)
+            with torch.no_grad():
+                enc_real = frozen_encoder.forward_log_mel_tensor(real_db_lp)
+            loss_sc = F.cross_entropy(style_critic(enc_real["z_style"].detach()), gidx, weight=class_w)
+            _backward_step(loss_sc, opt_sc, 0.0)
+            # D step (:816-840)
+            with torch.no_grad():
+                fake_det = generator(zc, cond)
+            loss_d = _gan_d_loss(stage_cfg.gan_loss, discriminator(real, cond_d), discriminator(fake_det, cond_d),
+                                 float(stage_cfg.d_real_label), float(stage_cfg.d_fake_label))
+            floor = float(stage_cfg.d_loss_floor_for_step)
+            if do_d_step and (floor <= 0.0 or float(loss_d.item()) >= floor):
+                _backward_step(loss_d, opt_d, stage_cfg.d_grad_clip_norm)
+                taken += 1
+            else:
+                skipped += 1
+            # G step (:842-1028)
+            fake = generator(zc, cond)
+            saved = [p.requires_grad for p in d_params]
+            for p in d_params:  # the reference lets D's weight gradients of this pass accumulate and then discards them
+                p.requires_grad_(False)
+            try:
+                logit_fake_g, d_fake_feat = discriminator(fake, cond_d, return_features=True)
+            finally:
+                for p, r in zip(d_params, saved):
+                    p.requires_grad_(r)
+            loss_adv = _gan_g_loss(stage_cfg.gan_loss, logit_fake_g, float(stage_cfg.g_real_label), float(stage_cfg.d_fake_label))
+            with torch.no_grad():
+                _, d_real_feat = discriminator(real, cond_d, return_features=True)
+            loss_fm = F.l1_loss(d_fake_feat, d_real_feat)
+            fake_db = denormalize_log_mel(fake)
+            enc_out = frozen_encoder.forward_log_mel_tensor(LL.lowpass_mel_db(fake_db, keep_bins=lp_bins))
+            enc_mid = frozen_encoder.forward_log_mel_tensor(LL.bandpass_mel_db(fake_db, low_bin=int(stage_cfg.style_mid_low_bin),
+                                                                              high_bin=int(stage_cfg.style_mid_high_bin)))
+            loss_content = LL.cosine_distance(enc_out["z_content"], zc).mean()
+            fake_zs = enc_out["z_style"]
+            style_logits = style_critic(fake_zs)
+            loss_style = F.cross_entropy(style_logits, tgt_idx, weight=class_w, label_smoothing=smoothing)
+            conf = torch.softmax(style_logits, dim=1).gather(1, tgt_idx.unsqueeze(1)).squeeze(1)
+            style_conf = conf.mean()
+            loss_style_mid = F.cross_entropy(style_critic(enc_mid["z_style"]), tgt_idx, weight=class_w, label_smoothing=smoothing)
+            loss_style_hinge = F.relu(float(stage_cfg.style_hinge_target_conf) - conf).mean()
+            proto_logits = F.normalize(fake_zs, dim=-1) @ protos.t() / float(stage_cfg.contrastive_temp)  # :572-578
+            loss_contrastive = F.cross_entropy(proto_logits, tgt_idx)
+            contrastive_conf = torch.softmax(proto_logits, dim=1).gather(1, tgt_idx.unsqueeze(1)).squeeze(1).mean()
+            with torch.no_grad():
+                enc_ref = frozen_encoder.forward_log_mel_tensor(real_db_lp[_target_reference_rows(gidx, tgt_idx)])
+            loss_pfm = (F.mse_loss(F.normalize(enc_out["shared_feat"], dim=-1), F.normalize(enc_ref["shared_feat"].detach(), dim=-1))
+                        + F.mse_loss(F.normalize(fake_zs, dim=-1), F.normalize(enc_ref["z_style"].detach(), dim=-1)))
+            loss_infonce = _within_genre_infonce(fake_zs, tgt_idx, float(stage_cfg.batch_infonce_temp))
+            loss_l1 = F.l1_loss(fake, real)
+            loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions)
+            loss_mrstft = loss_continuity
+            loss_lowmid = LL.frequency_weighted_l1_loss(fake, real, split_bin=int(stage_cfg.lowmid_split_bin),
+                                                        low_gain=float(stage_cfg.lowmid_gain), high_gain=float(stage_cfg.high_gain))
+            loss_highpass = LL.highpass_recon_l1_loss(fake, real, low_cut_bin=int(stage_cfg.highpass_cut_bin), gain=float(stage_cfg.highpass_gain))
+            loss_flat = LL.spectral_flatness_penalty_from_db(fake_db)
+            loss_timbre = LL.timbre_balance_penalty_from_db(fake_db)
+            loss_tilt = LL.spectral_tilt_penalty_from_db(fake_db, hf_to_lf_max_ratio=float(stage_cfg.spectral_tilt_max_ratio))
+            loss_zcr = LL.zcr_proxy_penalty_from_db(fake_db, target_max=float(stage_cfg.zcr_proxy_target_max))
+            loss_hf = LL.hf_excess_penalty_from_db(fake_db, real_db, top_frac=float(stage_cfg.hf_top_frac),
+                                                   max_ratio_multiplier=float(stage_cfg.hf_max_ratio_multiplier))
+            loss_perc = F.l1_loss(enc_out["shared_feat"], enc_real["shared_feat"].detach())
+            loss_div = _same_target_pair_hinge(d_fake_feat, tgt_idx, float(stage_cfg.diversity_margin), int(stage_cfg.diversity_max_pairs))
+            loss_mel_div = _same_target_pair_hinge(fake.flatten(1), tgt_idx, float(stage_cfg.mel_diversity_margin),
+                                                   int(stage_cfg.mel_diversity_max_pairs))
+            if target_profile_bank is not None:  # time-summed power per mel bin, as a distribution (:971-976)
+                prof = torch.pow(10.0, fake_db / 10.0).clamp_min(1e-10).sum(dim=2)
+                loss_prof = F.l1_loss(prof / (prof.sum(dim=1, keepdim=True) + 1e-8), target_profile_bank[tgt_idx])
+            else:
+                loss_prof = torch.zeros((), device=fake.device)
+            if stage_cfg.adaptive_content_weight:  # :980-990
+                cur = float((0.5 * style_conf + 0.5 * contrastive_conf).item())
+                ema_conf = cur if ema_conf is None else 0.9 * ema_conf + 0.1 * cur
+                if ema_conf < float(stage_cfg.adaptive_conf_low):
+                    content_w = float(stage_cfg.adaptive_content_low)
+                elif ema_conf > float(stage_cfg.adaptive_conf_high):
+                    content_w = float(stage_cfg.adaptive_content_high)
+            loss_g = (w.adv * loss_adv + w.recon_l1 * loss_l1 + w.continuity * loss_continuity + float(content_w) * loss_content
+                      + w.style * loss_style + w.style_mid * loss_style_mid + w.pfm_style * loss_pfm + w.style_hinge * loss_style_hinge
+                      + w.contrastive * loss_contrastive + w.batch_infonce_diversity * loss_infonce + w.mrstft * loss_mrstft
+                      + w.lowmid_recon * loss_lowmid + w.highpass_anchor * loss_highpass + w.flatness * loss_flat
+                      + w.timbre_balance * loss_timbre + w.spectral_tilt * loss_tilt + w.zcr_proxy * loss_zcr + w.hf_muzzle * loss_hf
+                      + w.feature_match * loss_fm + w.perceptual * loss_perc + w.diversity * loss_div + w.mel_diversity * loss_mel_div
+                      + w.target_profile * loss_prof)
+            opt_g.zero_grad(set_to_none=True)
+            style_critic.zero_grad(set_to_none=True)  # the critic is only an evaluator here; its own step zeroes before its backward
+            if thaw_active and opt_thaw is not None:
+                opt_thaw.zero_grad(set_to_none=True)
+            loss_g.backward()
+            clip = float(stage_cfg.g_grad_clip_norm)
+            opt_g.max_grad_norm = clip if clip > 0.0 else 0.0
+            opt_g.step()
+            if thaw_active and opt_thaw is not None:
+                if clip > 0.0 and thaw_params:
+                    torch.nn.utils.clip_grad_norm_(thaw_params, max_norm=clip)
+                opt_thaw.step()
+            zero = torch.zeros((), device=device)
+            row = (loss_g, loss_d, zero, loss_sc, loss_adv, loss_l1, loss_continuity, loss_mrstft, loss_content, loss_style, loss_style_mid,
+                   loss_pfm, loss_contrastive, loss_infonce, loss_style_hinge, loss_lowmid, loss_flat, loss_timbre, loss_tilt, loss_zcr, loss_hf,
+                   loss_highpass, loss_fm, loss_perc, loss_div, loss_mel_div, loss_prof)
+            host = torch.tensor([float(content_w), float(cur_lr_g), 0.0, 1.0 if thaw_active else 0.0, float(cond_alpha)], dtype=torch.float64)
+            vals = torch.cat([torch.stack([v.detach().double().reshape(()) for v in row]), host.to(device)])
+            vals[STAGE2_KEYS.index("style_conf")] = style_conf.detach().double()
+            sums += vals
+            nb += 1
+            step_idx += 1
+        means = (sums / nb).tolist() if nb > 0 else [float("nan")] * len(STAGE2_KEYS)
+        ep: Dict = {k: float(v) for k, v in zip(STAGE2_KEYS, means)}
+        ep.update(stage="stage2", epoch=int(epoch + 1), d_steps_taken=float(taken), d_steps_skipped=float(skipped),
+                  d_step_rate=float(taken / max(1, taken + skipped)))
+        history.append(ep)
+        _save_stage_checkpoint(checkpoint_path, int(epoch + 1), generator, discriminator, opt_g, opt_d, meta={"stage": "stage2"},
+                               style_critic=style_critic, opt_sc=opt_sc, frozen_encoder_model=frozen_encoder.model, opt_style_thaw=opt_thaw)
+        print(f"[stage2] epoch={epoch + 1} loss_g={ep['loss_g']:.4f} loss_d={ep['loss_d']:.4f}")
     return history

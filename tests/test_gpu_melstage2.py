@@ -1,0 +1,105 @@
+"""GPU: gan_amd.lab3_train.train_stage2 (generator / discriminator passes on the HIP kernels, fp32 mode) against the history rows and
+the checkpoint the REFERENCE's own train_stage2 produced on the same objects (tests/golden/melstage2_golden.npz, written by
+tests/golden/make_golden_melstage2.py; set-up shared through tests/mel_stage2_common.py, which explains how the random draws of the loop
+are made irrelevant).  Two cases: every one of the 23 generator terms weighted, bce, label smoothing, class weights, clipping, warm-up
+schedules (3 iterations); hinge, D every other step with a loss floor, content-conditioned D, adaptive content weight, thawed
+encoder layers in the last epoch (4 iterations).
+
+Bounds (measured in brackets): the first iteration's rows 2e-5 relative [1.2e-6: fp32 kernels against fp32 CPU torch, different summation
+orders]; the rows after one and two Adam steps 1e-2 [3.7e-4, 2.4e-3: the +-lr sign noise of zero-gradient parameters grows through
+the steps, tests/test_gpu_melgan.py]; the second case's rows are means over two iterations: 5e-3 [9.3e-4] and 3e-2 [7.5e-3].  Checkpoint
+tensors: every parameter within (steps x 2 lr) of the reference's in its sampled entries, sums within that times the element count."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, str(Path(__file__).parent))
+import mel_stage2_common as C  # noqa: E402
+from gan_amd import lab3_models as PM  # noqa: E402
+from gan_amd import lab3_train as PT  # noqa: E402
+from oracle.procfill import fill_state_dict  # noqa: E402
+
+DEV = torch.device("cuda")
+GOLD = np.load(Path(__file__).parent / "golden" / "melstage2_golden.npz")
+
+
+def fp(t):
+    d = t.detach().double().cpu().reshape(-1)
+    step = max(1, d.numel() // 8)
+    return np.concatenate([[d.sum().item(), d.abs().sum().item(), (d * d).sum().item()], d[::step][:8].numpy()])
+
+
+def run_case(case, tmp_path, monkeypatch):
+    kw, _, _ = C.CASES[case]
+    G = PM.ReconstructionDecoder(**C.G_KW)
+    G.load_state_dict(fill_state_dict(G.state_dict(), 21))
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM + (C.ZC_DIM if kw.get("disc_use_content_cond") else 0))
+    D.load_state_dict(fill_state_dict(D.state_dict(), 22))
+    G, D = G.to(DEV), D.to(DEV)
+    enc = C.ToyFrozenEncoder(DEV)
+    cond_bank, proto, prof = C.stage2_banks()
+    cfg = PT.StageTrainConfig(weights=PT.TrainWeights(**C.ALL_WEIGHTS), **kw)
+    monkeypatch.setattr(PT, "StyleCritic", lambda **k: PM.StyleCritic(dropout=0.0, **k))
+    ck = tmp_path / "stage2.pt"
+    torch.manual_seed(C.STAGE2_SEED)
+    hist = PT.train_stage2(G, D, enc, C.loader_for(case), cond_bank, proto, None, prof, DEV, cfg, ck, resume=False)
+    return hist, torch.load(ck, map_location="cpu", weights_only=True), cfg
+
+
+@pytest.mark.parametrize("case", list(C.CASES))
+def test_train_stage2_follows_the_reference_run(case, tmp_path, monkeypatch):
+    hist, payload, cfg = run_case(case, tmp_path, monkeypatch)
+    assert len(hist) == int(cfg.epochs)
+    steps = 0
+    worst = {}
+    for ep in hist:
+        e = ep["epoch"]
+        assert ep["stage"] == "stage2"
+        for k, v in ep.items():
+            if k == "stage":
+                continue
+            want = float(GOLD[f"stage2/{case}/hist/{e}/{k}"])
+            if k in ("epoch", "d_steps_taken", "d_steps_skipped", "d_step_rate", "content_weight", "lr_g", "style_thaw_active", "cond_alpha"):
+                assert abs(v - want) <= 1e-9 + 1e-6 * abs(want), (case, e, k, v, want)
+                continue
+            rtol = {("all_terms", 1): 2e-5, ("all_terms", 2): 1e-2, ("all_terms", 3): 1e-2, ("hinge_thaw", 1): 5e-3, ("hinge_thaw", 2): 3e-2}[(case, e)]
+            err = abs(v - want)
+            worst[(e, k)] = err / max(abs(want), 1e-3)
+            assert err <= rtol * abs(want) + (2e-6 if rtol < 1e-4 else 2e-4), (case, e, k, v, want)
+    print(case, "worst relative deviation per epoch:", {e: max(v for (ee, _), v in worst.items() if ee == e) for e in {ee for ee, _ in worst}})
+    assert sorted(payload.keys()) == GOLD[f"stage2/{case}/ckpt/keys"].tolist()
+    n_steps = sum(1 for _ in hist) * (1 if case == "all_terms" else 2)
+    for group, lr in (("generator", cfg.lr_g), ("discriminator", cfg.lr_d), ("style_critic", cfg.style_critic_lr),
+                      ("frozen_encoder_model", cfg.style_thaw_lr)):
+        for k, v in payload[group].items():
+            if not v.dtype.is_floating_point:
+                continue
+            want = GOLD[f"stage2/{case}/ckpt/{group}/{k}"]
+            got = fp(v)
+            per = 2.0 * float(lr) * n_steps + 1e-5
+            if "running_" in k:  # BatchNorm statistics of activations, not Adam-stepped: relative
+                assert np.all(np.abs(got[3:] - want[3:]) <= 3e-2 * np.abs(want[3:]) + 1e-3), (case, group, k, got[3:], want[3:])
+                continue
+            assert np.all(np.abs(got[3:] - want[3:]) <= per + 1e-5 * np.abs(want[3:])), (case, group, k, got[3:], want[3:])
+            assert abs(got[0] - want[0]) <= per * v.numel(), (case, group, k, "sum", got[0], want[0])
+    # the thawed layers moved (case 2) and the rest of the caller's encoder did not
+    if case == "hinge_thaw":
+        ref0 = C.ToyFrozenEncoder("cpu").model.state_dict()
+        moved = {k: float((payload["frozen_encoder_model"][k] - ref0[k]).abs().max()) for k in ref0 if ref0[k].dtype.is_floating_point}
+        assert moved["shared.weight"] > 0 and moved["style_head.weight"] > 0 and moved["content_head.weight"] == 0 and moved["backbone.0.weight"] == 0
+
+
+def test_stage2_refuses_what_it_does_not_implement(tmp_path):
+    cfg = PT.StageTrainConfig(stage_name="stage2", epochs=1, r1_gamma=1.0)
+    with pytest.raises(NotImplementedError):
+        PT.train_stage2(None, None, None, [], torch.zeros(2, 4), torch.zeros(2, 4), None, None, DEV, cfg, tmp_path / "x.pt")
+    G = PM.ReconstructionDecoder(**C.G_KW).to(DEV)
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM).to(DEV)
+    cfg = PT.StageTrainConfig(stage_name="stage2", epochs=1, style_thaw_scope="everything")
+    with pytest.raises(ValueError):
+        PT.train_stage2(G, D, C.ToyFrozenEncoder(DEV), [], torch.zeros(2, C.COND_DIM), torch.zeros(2, C.ZC_DIM), None, None, DEV, cfg, tmp_path / "x.pt")
