@@ -11,7 +11,9 @@ and LeakyReLU in its epilogue where they follow directly.  ConvTranspose2d(k4, s
 channels (each output phase uses a 2x2 subset of the 4x4 kernel) followed by the pixel shuffle.  The parameters live in ordinary
 torch layers (that is what keeps the keys and the initialisation identical); normalisation layers, activations between them, the
 pooled heads and the Linear layers run as the torch modules they are (which parts of the mel track are
-HIP and which are not).  Spectral norm is not supported (the reference's default is off): asking for it raises.
+HIP and which are not).  spectral_norm=True wraps the same layers the reference wraps (:77-78, :152-153) with torch's own
+`nn.utils.spectral_norm`, so the `weight_orig` / `weight_u` / `weight_v` keys, the one power iteration per training-mode forward and
+the gradient through sigma are torch's; the normalised weight it produces is what the HIP convolution packs and multiplies.
 """
 from __future__ import annotations
 
@@ -21,13 +23,23 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from torch.nn.utils.spectral_norm import SpectralNorm
+
 from . import _lib as L
 from .conv2d import conv2d_nhwc, conv_transpose2d_k4s2p1_nhwc, to_nchw_view, to_nhwc
 
 
-def _no_sn(flag: bool) -> None:
-    if bool(flag):
-        raise NotImplementedError("spectral_norm=True is not supported by the HIP mel-track modules (reference default: False)")
+def _maybe_sn(layer: nn.Module, flag: bool) -> nn.Module:
+    return nn.utils.spectral_norm(layer) if bool(flag) else layer
+
+
+def _weight_of(m: nn.Module) -> torch.Tensor:
+    """The layer's weight as its own forward would see it: a spectral-norm layer recomputes `weight` in a forward pre-hook (power
+    iteration in training mode, then weight_orig / sigma), which has to be run by hand because the layer's forward is not called."""
+    for hook in m._forward_pre_hooks.values():
+        if isinstance(hook, SpectralNorm):
+            hook(m, None)
+    return m.weight
 
 
 def _dtype(precision: str) -> torch.dtype:
@@ -49,11 +61,11 @@ def _run(layers: Sequence[nn.Module], h: torch.Tensor) -> torch.Tensor:
             if isinstance(m, nn.ConvTranspose2d):
                 if tuple(m.kernel_size) != (4, 4) or tuple(m.stride) != (2, 2) or tuple(m.padding) != (1, 1):
                     raise NotImplementedError("only ConvTranspose2d(kernel 4, stride 2, padding 1) is mapped (the decoder's up-blocks)")
-                y = conv_transpose2d_k4s2p1_nhwc(x, m.weight, m.bias, act)
+                y = conv_transpose2d_k4s2p1_nhwc(x, _weight_of(m), m.bias, act)
             else:
                 if m.stride[0] != m.stride[1] or m.padding[0] != m.padding[1] or tuple(m.dilation) != (1, 1) or m.groups != 1:
                     raise NotImplementedError("square stride / padding, no dilation, no groups")
-                y = conv2d_nhwc(x, m.weight, m.bias, int(m.stride[0]), int(m.padding[0]), act)
+                y = conv2d_nhwc(x, _weight_of(m), m.bias, int(m.stride[0]), int(m.padding[0]), act)
             h = to_nchw_view(y)
             i += 2 if fuse else 1
             continue
@@ -99,7 +111,7 @@ class ReconstructionDecoder(nn.Module):
         super().__init__()
         if n_mels % 8 != 0 or n_frames % 8 != 0:
             raise ValueError("n_mels and n_frames must be divisible by 8.")
-        _no_sn(spectral_norm)
+        sn = bool(spectral_norm)
         self.n_mels, self.n_frames = int(n_mels), int(n_frames)
         self.h0, self.w0 = self.n_mels // 8, self.n_frames // 8
         self.base = int(base_channels)
@@ -117,20 +129,21 @@ class ReconstructionDecoder(nn.Module):
 
         def up_block(cin, cout):  # the layer ORDER fixes the state_dict indices (up1.0 / up1.1 / up1.2 ...)
             if up_key == "transpose":
-                return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1), norm2d(cout), nn.LeakyReLU(0.2, inplace=True))
+                return nn.Sequential(_maybe_sn(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1), sn), norm2d(cout),
+                                     nn.LeakyReLU(0.2, inplace=True))
             if up_key == "nearest":
-                return nn.Sequential(nn.Upsample(scale_factor=2, mode="nearest"), nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1),
+                return nn.Sequential(nn.Upsample(scale_factor=2, mode="nearest"), _maybe_sn(nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1), sn),
                                      norm2d(cout), nn.LeakyReLU(0.2, inplace=True))
-            return nn.Sequential(nn.Conv2d(cin, cout * 4, kernel_size=3, stride=1, padding=1), nn.PixelShuffle(2), norm2d(cout),
+            return nn.Sequential(_maybe_sn(nn.Conv2d(cin, cout * 4, kernel_size=3, stride=1, padding=1), sn), nn.PixelShuffle(2), norm2d(cout),
                                  nn.LeakyReLU(0.2, inplace=True))
 
         b = self.base
-        self.fc = nn.Linear(int(zc_dim + cond_dim), b * self.h0 * self.w0)
+        self.fc = _maybe_sn(nn.Linear(int(zc_dim + cond_dim), b * self.h0 * self.w0), sn)
         self.up1, self.up2, self.up3 = up_block(b, b // 2), up_block(b // 2, b // 4), up_block(b // 4, b // 8)
         self.mrf1 = MRFResidualBlock(b // 2, kernels=mrf_kernels) if mrf else nn.Identity()
         self.mrf2 = MRFResidualBlock(b // 4, kernels=mrf_kernels) if mrf else nn.Identity()
         self.mrf3 = MRFResidualBlock(b // 8, kernels=mrf_kernels) if mrf else nn.Identity()
-        self.out = nn.Conv2d(b // 8, 1, kernel_size=3, stride=1, padding=1)
+        self.out = _maybe_sn(nn.Conv2d(b // 8, 1, kernel_size=3, stride=1, padding=1), sn)
 
     def forward(self, z_content: torch.Tensor, v_target: torch.Tensor) -> torch.Tensor:
         L.require_cuda(z_content, v_target)
@@ -149,18 +162,19 @@ class MelDiscriminator(nn.Module):
 
     def __init__(self, in_channels: int = 1, base_channels: int = 64, cond_dim: int = 0, spectral_norm: bool = False, precision: str = "fp32"):
         super().__init__()
-        _no_sn(spectral_norm)
+        sn = bool(spectral_norm)
         c = int(base_channels)
         self.cond_dim = int(cond_dim)
         self.precision = precision
         self._dt = _dtype(precision)
-        layers = [nn.Conv2d(in_channels, c, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(0.2, inplace=True)]
+        layers = [_maybe_sn(nn.Conv2d(in_channels, c, kernel_size=4, stride=2, padding=1), sn), nn.LeakyReLU(0.2, inplace=True)]
         for k in (1, 2, 4):
-            layers += [nn.Conv2d(c * k, c * k * 2, kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(c * k * 2), nn.LeakyReLU(0.2, inplace=True)]
+            layers += [_maybe_sn(nn.Conv2d(c * k, c * k * 2, kernel_size=4, stride=2, padding=1), sn), nn.BatchNorm2d(c * k * 2),
+                       nn.LeakyReLU(0.2, inplace=True)]
         layers.append(nn.AdaptiveAvgPool2d((1, 1)))
         self.net = nn.Sequential(*layers)
-        self.head = nn.Linear(c * 8, 1)
-        self.cond_proj = nn.Linear(self.cond_dim, c * 8) if self.cond_dim > 0 else None
+        self.head = _maybe_sn(nn.Linear(c * 8, 1), sn)
+        self.cond_proj = _maybe_sn(nn.Linear(self.cond_dim, c * 8), sn) if self.cond_dim > 0 else None
 
     def forward(self, mel_norm: torch.Tensor, cond: Optional[torch.Tensor] = None, return_features: bool = False):
         L.require_cuda(mel_norm)

@@ -8,7 +8,9 @@ soundfile, as make_golden_melgan.py does) and records
   * every penalty of lab3_losses.py (:74-286) on a procedural dB mel: value and input-gradient fingerprint, the masks of
     lowpass_mel_db / bandpass_mel_db, estimate_lowpass_keep_bins on a few arguments;
   * the history rows train_stage2 (lab3_train.py:486-1088) returns for the two cases of tests/mel_stage2_common.py, and fingerprints
-    of every tensor of the checkpoint it writes (generator, discriminator, style critic, the thawed encoder).
+    of every tensor of the checkpoint it writes (generator, discriminator, style critic, the thawed encoder);
+  * ReconstructionDecoder / MelDiscriminator with spectral_norm=True: state-dict keys, two training passes, gradients, u / v buffers,
+    an eval pass.
 The only change made to the reference while it runs: StyleCritic is built with dropout 0 (see mel_stage2_common.py).
 """
 from __future__ import annotations
@@ -92,6 +94,40 @@ def penalty_cases():
     put("pen/keep_bins", np.asarray([RL.estimate_lowpass_keep_bins(n, sr, c) for n, sr, c in C.KEEP_BIN_ARGS], dtype=np.int64))
 
 
+def spectral_norm_cases():
+    """spectral_norm=True (lab3_models.py:77-78, :152-153): two training-mode passes (u / v advance one power iteration each), the
+    parameter gradients of the second, the u / v buffers after it, then an eval-mode pass (no power iteration)."""
+    G = RM.ReconstructionDecoder(zc_dim=16, cond_dim=8, n_mels=16, n_frames=32, base_channels=32, spectral_norm=True)
+    G.load_state_dict(fill_state_dict(G.state_dict(), 41))
+    D = RM.MelDiscriminator(base_channels=16, cond_dim=8, spectral_norm=True)
+    D.load_state_dict(fill_state_dict(D.state_dict(), 42))
+    G.train(), D.train()
+    put("sn/keys_g", np.asarray(list(G.state_dict().keys())))
+    put("sn/keys_d", np.asarray(list(D.state_dict().keys())))
+    zc, v = proc_input((3, 16), "melsn.zc", 0), proc_input((3, 8), "melsn.v", 0)
+    mel_in = proc_input((3, 32, 64), "melsn.mel", 0, 0.8)
+    for rep in (0, 1):
+        mel = G(zc, v)
+        logit, feat = D(mel_in, v, return_features=True)
+        put(f"sn/{rep}/g_out_fp", fp(mel))
+        put(f"sn/{rep}/d_logit", logit)
+        put(f"sn/{rep}/d_feat_fp", fp(feat))
+    loss_g = (mel ** 2).mean() + 0.1 * mel.abs().mean()
+    for (n, _), g in zip(G.named_parameters(), torch.autograd.grad(loss_g, list(G.parameters()))):
+        put(f"sn/g_grad/{n}", fp(g))
+    loss_d = torch.nn.functional.softplus(-logit).mean() + 0.01 * feat.pow(2).mean()
+    for (n, _), g in zip(D.named_parameters(), torch.autograd.grad(loss_d, list(D.parameters()))):
+        put(f"sn/d_grad/{n}", fp(g))
+    for tag, mod in (("g", G), ("d", D)):
+        for n, b in mod.named_buffers():
+            if n.endswith("weight_u") or n.endswith("weight_v"):
+                put(f"sn/{tag}_buf/{n}", b)
+    G.eval(), D.eval()
+    with torch.no_grad():
+        put("sn/eval/g_out_fp", fp(G(zc, v)))
+        put("sn/eval/d_logit", D(mel_in, v))
+
+
 def stage2_case(case: str):
     kw, _, _ = C.CASES[case]
     G = RM.ReconstructionDecoder(**C.G_KW)
@@ -122,6 +158,7 @@ def stage2_case(case: str):
 
 def main():
     penalty_cases()
+    spectral_norm_cases()
     for case in C.CASES:
         stage2_case(case)
     path = HERE / "melstage2_golden.npz"

@@ -103,3 +103,39 @@ def test_stage2_refuses_what_it_does_not_implement(tmp_path):
     cfg = PT.StageTrainConfig(stage_name="stage2", epochs=1, style_thaw_scope="everything")
     with pytest.raises(ValueError):
         PT.train_stage2(G, D, C.ToyFrozenEncoder(DEV), [], torch.zeros(2, C.COND_DIM), torch.zeros(2, C.ZC_DIM), None, None, DEV, cfg, tmp_path / "x.pt")
+
+
+def test_spectral_norm_modules_match_the_reference():
+    """spectral_norm=True: same state-dict keys as the reference's modules, and two training passes, gradients, power-iteration buffers
+    and an eval pass against the reference's (fixtures `sn/*`)."""
+    import torch.nn.functional as F
+    from oracle.procfill import proc_input
+    from test_gpu_melgan import close, fp_close
+    G = PM.ReconstructionDecoder(zc_dim=16, cond_dim=8, n_mels=16, n_frames=32, base_channels=32, spectral_norm=True)
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=8, spectral_norm=True)
+    assert list(G.state_dict().keys()) == GOLD["sn/keys_g"].tolist() and list(D.state_dict().keys()) == GOLD["sn/keys_d"].tolist()
+    G.load_state_dict(fill_state_dict(G.state_dict(), 41))
+    D.load_state_dict(fill_state_dict(D.state_dict(), 42))
+    G, D = G.to(DEV).train(), D.to(DEV).train()
+    zc, v = proc_input((3, 16), "melsn.zc", 0).to(DEV), proc_input((3, 8), "melsn.v", 0).to(DEV)
+    mel_in = proc_input((3, 32, 64), "melsn.mel", 0, 0.8).to(DEV)
+    for rep in (0, 1):
+        mel = G(zc, v)
+        logit, feat = D(mel_in, v, return_features=True)
+        fp_close(mel, GOLD[f"sn/{rep}/g_out_fp"], f"pass {rep} decoder", rtol=1e-4)
+        close(logit.detach().cpu().numpy(), GOLD[f"sn/{rep}/d_logit"], atol=2e-6, what=f"pass {rep} logit")
+        fp_close(feat, GOLD[f"sn/{rep}/d_feat_fp"], f"pass {rep} features", rtol=1e-4)
+    loss_g = (mel ** 2).mean() + 0.1 * mel.abs().mean()
+    for (n, _), g in zip(G.named_parameters(), torch.autograd.grad(loss_g, list(G.parameters()))):
+        fp_close(g, GOLD[f"sn/g_grad/{n}"], f"decoder grad {n}", rtol=3e-4)
+    loss_d = F.softplus(-logit).mean() + 0.01 * feat.pow(2).mean()
+    for (n, _), g in zip(D.named_parameters(), torch.autograd.grad(loss_d, list(D.parameters()))):
+        fp_close(g, GOLD[f"sn/d_grad/{n}"], f"discriminator grad {n}", rtol=3e-4)
+    for tag, mod in (("g", G), ("d", D)):
+        for n, b in mod.named_buffers():
+            if n.endswith("weight_u") or n.endswith("weight_v"):
+                close(b.cpu().numpy(), GOLD[f"sn/{tag}_buf/{n}"], rtol=1e-4, atol=1e-6, what=n)
+    G.eval(), D.eval()
+    with torch.no_grad():
+        fp_close(G(zc, v), GOLD["sn/eval/g_out_fp"], "eval decoder", rtol=1e-4)
+        close(D(mel_in, v).cpu().numpy(), GOLD["sn/eval/d_logit"], atol=2e-6, what="eval logit")

@@ -41,8 +41,8 @@ def test_constructor_errors_and_unsupported_options():
         PM.ReconstructionDecoder(norm="layer")
     with pytest.raises(ValueError):
         PM.MultiScaleMelDiscriminator(num_scales=0)
-    with pytest.raises(NotImplementedError):
-        PM.MelDiscriminator(spectral_norm=True)
+    sn_keys = set(PM.MelDiscriminator(base_channels=16, cond_dim=8, spectral_norm=True).state_dict())  # torch's spectral_norm layout
+    assert {"net.0.weight_orig", "net.0.weight_u", "net.0.weight_v", "head.weight_orig", "cond_proj.weight_u"} <= sn_keys and "net.0.weight" not in sn_keys
     with pytest.raises(ValueError):
         PT._gan_d_loss("wgan", torch.zeros(2), torch.zeros(2), 1.0, 0.0)
     cfg = PT.StageTrainConfig(stage_name="stage1", epochs=1)
