@@ -32,6 +32,21 @@ def to_nchw_view(y_nhwc: torch.Tensor) -> torch.Tensor:
     return y_nhwc.permute(0, 3, 1, 2)
 
 
+TWICE_DIFFERENTIABLE = False  # set by `twice_differentiable()`: convolutions become ops.ConvTwice nodes (gradient penalties)
+
+
+class twice_differentiable:
+    """Context: 2-D convolutions issued inside build a graph whose backward can itself be differentiated (`create_graph=True`)."""
+
+    def __enter__(self):
+        global TWICE_DIFFERENTIABLE
+        self._was, TWICE_DIFFERENTIABLE = TWICE_DIFFERENTIABLE, True
+
+    def __exit__(self, *exc):
+        global TWICE_DIFFERENTIABLE
+        TWICE_DIFFERENTIABLE = self._was
+
+
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int,
                 post_act: int = L.ACT_NONE) -> torch.Tensor:
     """x [B, H, W, C] (fp32 or bf16, contiguous), weight [M, C, kh, kw] and bias [M] (fp32 parameters) -> [B, OH, OW, M] in x's dtype."""
@@ -56,6 +71,9 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if kc8 != kc:
         w1 = F.pad(w1, (0, 0, 0, kc8 - kc))
     geom = ConvGeom("conv", kc8, M, kw, s, p, 1)
+    if TWICE_DIFFERENTIABLE:
+        y = ops.ConvTwice.apply(xr.view(B * OH, W, kc8), w1.contiguous(), bias, geom).view(B, OH, geom.out_len(W), M)
+        return F.leaky_relu(y, 0.2) if post_act == L.ACT_LRELU else y
     wp_f, wp_d, carrier = ops.PackTrainable.apply(w1.contiguous(), None, geom, x.dtype)
     y = ops.ConvTrain.apply(xr.view(B * OH, W, kc8), wp_f, wp_d, carrier, bias, geom, post_act, None)
     return y.view(B, OH, geom.out_len(W), M)

@@ -5,7 +5,8 @@ SURVEY.md section 8(f) next-4: `TrainWeights` (:31-56), `StageTrainConfig` (:58-
 names, arguments, history rows and checkpoint keys; one pass of a loop body is `mel_stage1_iteration` / `Stage2Runner.iteration`.
 Adam (torch.optim.Adam at :357-358, :538-540) and the optional gradient clipping run as the fused clip + AdamW kernel with weight
 decay 0; the optimizer of the caller's thawed encoder parameters (:532-536) stays torch.optim.Adam, on the caller's own module.
-Not implemented: R1 (:329-339, a double backward through BatchNorm) -- r1_gamma > 0 raises.
+R1 (:329-339) differentiates the discriminator's input gradient: inside `_r1_penalty` the 2-D convolutions run as twice-differentiable
+nodes (ops.ConvTwice: the same three HIP kernels in permuted roles), BatchNorm's double backward is torch's.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import lab3_losses as LL
+from .conv2d import twice_differentiable
 from .lab3_losses import multi_resolution_stft_loss
 from .lab3_models import StyleCritic, bce_logits
 from .optim import FusedAdamW
@@ -215,6 +217,15 @@ def _gan_g_loss(gan_loss: str, logits_fake: torch.Tensor, g_real_label: float, d
     raise ValueError(f"Unsupported gan_loss: {gan_loss}")
 
 
+def _r1_penalty(discriminator, real: torch.Tensor, cond: Optional[torch.Tensor]) -> torch.Tensor:
+    """reference lab3_train.py:329-339: mean over the batch of || d sum(logits) / d real ||^2, with a graph behind it."""
+    real_req = real.detach().requires_grad_(True)
+    with twice_differentiable():
+        logits = discriminator(real_req, cond)
+        grad, = torch.autograd.grad(outputs=logits.sum(), inputs=real_req, create_graph=True, retain_graph=True, only_inputs=True)
+    return grad.pow(2).reshape(grad.shape[0], -1).sum(dim=1).mean()
+
+
 def denormalize_log_mel(mel_norm: torch.Tensor) -> torch.Tensor:
     """reference lab3_bridge.py:135-139: [-1, 1] -> dB."""
     return (torch.clamp(mel_norm, -1.0, 1.0) + 1.0) * (0.5 * (MEL_DB_MAX - MEL_DB_MIN)) + MEL_DB_MIN
@@ -238,8 +249,6 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
     """One pass of train_stage1's loop body (reference lab3_train.py:380-456).  Returns device scalars (no host sync).
     frozen_encoder (+ zs): the caller's frozen Lab1 encoder for the content / style terms (:432-435); without it they stay at
     zero and nonzero weights for them are an error, not a silent drop."""
-    if float(stage_cfg.r1_gamma) > 0.0:
-        raise NotImplementedError("R1 on the mel discriminator (a double backward through BatchNorm) is not implemented")
     w = stage_cfg.weights
     if frozen_encoder is None and (float(w.content) != 0.0 or float(w.style) != 0.0) and not stage_cfg.extra.get("allow_missing_encoder", False):
         raise ValueError("weights.content / weights.style need the frozen Lab1 encoder (pass frozen_encoder, or set them to 0)")
@@ -251,7 +260,12 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
         fake_det = generator(zc, cond)
     loss_d = _gan_d_loss(stage_cfg.gan_loss, discriminator(real, cond_d), discriminator(fake_det, cond_d),
                          float(stage_cfg.d_real_label), float(stage_cfg.d_fake_label))
+    zero = torch.zeros((), device=real.device)
+    r1 = zero
     if do_d_step:
+        if float(stage_cfg.r1_gamma) > 0.0 and (int(step_idx) % int(max(1, stage_cfg.r1_interval)) == 0):
+            r1 = 0.5 * float(stage_cfg.r1_gamma) * _r1_penalty(discriminator, real, cond_d)
+            loss_d = loss_d + r1
         _backward_step(loss_d, opt_d, stage_cfg.d_grad_clip_norm)
     # G step (:418-451)
     fake = generator(zc, cond)
@@ -268,7 +282,6 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
     loss_l1 = F.l1_loss(fake, real)
     loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions)
     loss_mrstft = loss_continuity
-    zero = torch.zeros((), device=real.device)
     loss_content = loss_style = zero
     if frozen_encoder is not None:
         enc = frozen_encoder.forward_log_mel_tensor(denormalize_log_mel(fake))
@@ -278,7 +291,7 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
     loss_g = (w.adv * loss_adv + w.recon_l1 * loss_l1 + w.content * loss_content + w.style * loss_style
               + w.continuity * loss_continuity + w.mrstft * loss_mrstft)
     _backward_step(loss_g, opt_g, stage_cfg.g_grad_clip_norm)
-    out.update(loss_g=loss_g.detach(), loss_d=loss_d.detach(), loss_r1=zero, loss_adv=loss_adv.detach(), loss_l1=loss_l1.detach(),
+    out.update(loss_g=loss_g.detach(), loss_d=loss_d.detach(), loss_r1=r1.detach(), loss_adv=loss_adv.detach(), loss_l1=loss_l1.detach(),
                loss_content=loss_content.detach(), loss_style=loss_style.detach(), loss_continuity=loss_continuity.detach(),
                loss_mrstft=loss_mrstft.detach(), d_step=torch.tensor(1.0 if do_d_step else 0.0))
     return out
@@ -462,8 +475,6 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
     passes run on the HIP kernels; the frozen encoder is the caller's module; the 20-odd scalar penalties are device tensor expressions
     (lab3_losses.py).  Host reads per iteration: the D loss when `d_loss_floor_for_step` is set and the two confidences when
     `adaptive_content_weight` is -- both are data-dependent control flow in the reference; the history sums stay on the device."""
-    if float(stage_cfg.r1_gamma) > 0.0:
-        raise NotImplementedError("R1 on the mel discriminator (a double backward through BatchNorm) is not implemented")
     generator.train()
     discriminator.train()
     cond_bank = cond_bank.to(device)
@@ -543,6 +554,10 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
                 fake_det = generator(zc, cond)
             loss_d = _gan_d_loss(stage_cfg.gan_loss, discriminator(real, cond_d), discriminator(fake_det, cond_d),
                                  float(stage_cfg.d_real_label), float(stage_cfg.d_fake_label))
+            r1 = torch.zeros((), device=device)
+            if do_d_step and float(stage_cfg.r1_gamma) > 0.0 and (step_idx % int(max(1, stage_cfg.r1_interval)) == 0):
+                r1 = 0.5 * float(stage_cfg.r1_gamma) * _r1_penalty(discriminator, real, cond_d)
+                loss_d = loss_d + r1
             floor = float(stage_cfg.d_loss_floor_for_step)
             if do_d_step and (floor <= 0.0 or float(loss_d.item()) >= floor):
                 _backward_step(loss_d, opt_d, stage_cfg.d_grad_clip_norm)
@@ -630,8 +645,7 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
                 if clip > 0.0 and thaw_params:
                     torch.nn.utils.clip_grad_norm_(thaw_params, max_norm=clip)
                 opt_thaw.step()
-            zero = torch.zeros((), device=device)
-            row = (loss_g, loss_d, zero, loss_sc, loss_adv, loss_l1, loss_continuity, loss_mrstft, loss_content, loss_style, loss_style_mid,
+            row = (loss_g, loss_d, r1, loss_sc, loss_adv, loss_l1, loss_continuity, loss_mrstft, loss_content, loss_style, loss_style_mid,
                    loss_pfm, loss_contrastive, loss_infonce, loss_style_hinge, loss_lowmid, loss_flat, loss_timbre, loss_tilt, loss_zcr, loss_hf,
                    loss_highpass, loss_fm, loss_perc, loss_div, loss_mel_div, loss_prof)
             host = torch.tensor([float(content_w), float(cur_lr_g), 0.0, 1.0 if thaw_active else 0.0, float(cond_alpha)], dtype=torch.float64)

@@ -755,6 +755,76 @@ class ConvTrain(torch.autograd.Function):
         return gx, None, None, gw, gb, None, None, None
 
 
+def _unpack_wgrad(geom: ConvGeom, dw_packed: Tensor) -> Tensor:
+    d0, d1, k = geom.wdims
+    dw = torch.empty((d0, d1, k), device=dw_packed.device, dtype=torch.float32)
+    L.check(L.lib().ga_unpack_grad(dw_packed.contiguous().data_ptr(), dw.data_ptr(), geom.fwd_pack, d0, d1, k, geom.stride, geom.padding, 0,
+                                   L.stream()), "ga_unpack_grad")
+    return dw
+
+
+class ConvTwice(torch.autograd.Function):
+    """y = conv(x, w) + bias for a plain 'conv' layer, differentiable TWICE: its backward is built from the two autograd nodes below, so
+    a gradient penalty (R1: the squared norm of d logits / d input, reference lab 3/src/lab3_train.py:329-339) can be differentiated
+    with respect to the weights.  A convolution is bilinear in (x, w), so every derivative of every order is one of the same three
+    kernels with the operands in other roles: forward (ga_conv), data gradient (ga_conv, dgrad form), weight gradient (ga_wgrad).
+    w is the [cout, cin, k] fp32 weight itself (packed per call, no cache); no fused activation (the caller applies it as a tensor op)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, geom: ConvGeom):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.geom = geom
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return conv_forward(geom, x, pack_weight(geom, w, geom.fwd_pack, x.dtype), bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _ConvDataGrad.apply(gy, w, ctx.geom, x.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = _ConvWeightGrad.apply(gy, x, ctx.geom) if ctx.needs_input_grad[1] else None
+        gb = gy.float().sum(dim=(0, 1)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+class _ConvDataGrad(torch.autograd.Function):
+    """gx = dgrad(gy, w); linear in each: d<ggx, gx>/d gy = conv(ggx, w), d<ggx, gx>/d w = wgrad(gy, ggx)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, geom: ConvGeom, lin: int):
+        gy = gy.contiguous()
+        ctx.geom = geom
+        ctx.save_for_backward(gy, w)
+        return conv_dgrad(geom, gy, pack_weight(geom, w, geom.dgrad_pack, gy.dtype), lin)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        ggx = ggx.contiguous()
+        g_gy = ConvTwice.apply(ggx, w, None, ctx.geom) if ctx.needs_input_grad[0] else None
+        g_w = _ConvWeightGrad.apply(gy, ggx, ctx.geom) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None
+
+
+class _ConvWeightGrad(torch.autograd.Function):
+    """gw = wgrad(gy, x) in the [cout, cin, k] layout; d<ggw, gw>/d gy = conv(x, ggw), d<ggw, gw>/d x = dgrad(gy, ggw)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, geom: ConvGeom):
+        gy, x = gy.contiguous(), x.contiguous()
+        ctx.geom = geom
+        ctx.save_for_backward(gy, x)
+        return _unpack_wgrad(geom, conv_wgrad(geom, gy, x))
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        ggw = ggw.contiguous()
+        g_gy = ConvTwice.apply(x, ggw, None, ctx.geom) if ctx.needs_input_grad[0] else None
+        g_x = _ConvDataGrad.apply(gy, ggw, ctx.geom, x.shape[1]) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x, None
+
+
 class DiscChain(torch.autograd.Function):
     """A whole single-scale waveform discriminator (reference lab3_codec_models.py:131-152): n-1 x [conv + bias +
     LeakyReLU(0.2)] and the logits conv, as ONE autograd node, so that the backward pass can fuse across layers what

@@ -9,6 +9,7 @@ soundfile, as make_golden_melgan.py does) and records
     lowpass_mel_db / bandpass_mel_db, estimate_lowpass_keep_bins on a few arguments;
   * the history rows train_stage2 (lab3_train.py:486-1088) returns for the two cases of tests/mel_stage2_common.py, and fingerprints
     of every tensor of the checkpoint it writes (generator, discriminator, style critic, the thawed encoder);
+  * _r1_penalty (:329-339): value, parameter gradients, BatchNorm buffers; train_stage1 with R1 on;
   * ReconstructionDecoder / MelDiscriminator with spectral_norm=True: state-dict keys, two training passes, gradients, u / v buffers,
     an eval pass.
 The only change made to the reference while it runs: StyleCritic is built with dropout 0 (see mel_stage2_common.py).
@@ -128,6 +129,45 @@ def spectral_norm_cases():
         put("sn/eval/d_logit", D(mel_in, v))
 
 
+def r1_cases():
+    """_r1_penalty (lab3_train.py:329-339) on a training-mode discriminator with the projection head: value, the gradient of
+    0.5 * gamma * penalty with respect to every parameter, BatchNorm buffers after the call; then the same through the multi-scale
+    wrapper (value only), and two passes of train_stage1's D step with R1 on the first (loss_d, loss_r1, parameters after)."""
+    D = RM.MelDiscriminator(base_channels=16, cond_dim=8)
+    D.load_state_dict(fill_state_dict(D.state_dict(), 52))
+    D.train()
+    real = proc_input((4, 32, 64), "melr1.real", 0, 0.8)
+    cond = proc_input((4, 8), "melr1.cond", 0)
+    pen = RT._r1_penalty(D, real, cond)
+    put("r1/penalty", pen)
+    for (n, _), g in zip(D.named_parameters(), torch.autograd.grad(0.5 * 2.0 * pen, list(D.parameters()), allow_unused=True)):
+        put(f"r1/grad/{n}", fp(g if g is not None else torch.zeros(1)))
+    for n, b in D.named_buffers():
+        if b.dtype.is_floating_point:
+            put(f"r1/buf/{n}", b)
+    MS = RM.MultiScaleMelDiscriminator(cond_dim=8, base_channels=16)
+    MS.load_state_dict(fill_state_dict(MS.state_dict(), 53))
+    put("r1/multiscale_penalty", RT._r1_penalty(MS.train(), proc_input((2, 64, 128), "melr1.real_ms", 0, 0.8), cond[:2]))
+    # train_stage1 with R1 every second step, content / style terms off (no encoder needed): two batches
+    G = RM.ReconstructionDecoder(**C.G_KW)
+    G.load_state_dict(fill_state_dict(G.state_dict(), 21))
+    D = RM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM)
+    D.load_state_dict(fill_state_dict(D.state_dict(), 22))
+    cfg = RT.StageTrainConfig(stage_name="stage1", epochs=2, max_batches_per_epoch=1, gan_loss="hinge", r1_gamma=2.0, r1_interval=2,
+                              weights=RT.TrainWeights(content=0.0, style=0.0), mrstft_resolutions=((16, 4, 16), (32, 8, 32), (64, 16, 64)))
+    enc = C.ToyFrozenEncoder("cpu")
+    cond_bank, _, _ = C.stage2_banks()
+    with tempfile.TemporaryDirectory() as td:
+        hist = RT.train_stage1(G, D, enc, C.ListLoader(C.stage2_batches(1), [0, 1, 2]), cond_bank, "cpu", cfg, Path(td) / "s1.pt")
+    for ep in hist:
+        for k, v in ep.items():
+            if k != "stage":
+                put(f"r1/stage1/hist/{ep['epoch']}/{k}", np.float64(v))
+    for n, p_ in D.named_parameters():
+        put(f"r1/stage1/d_param/{n}", fp(p_))
+    print("r1", float(pen), {k: round(v, 5) for k, v in hist[0].items() if isinstance(v, float)})
+
+
 def stage2_case(case: str):
     kw, _, _ = C.CASES[case]
     G = RM.ReconstructionDecoder(**C.G_KW)
@@ -159,6 +199,7 @@ def stage2_case(case: str):
 def main():
     penalty_cases()
     spectral_norm_cases()
+    r1_cases()
     for case in C.CASES:
         stage2_case(case)
     path = HERE / "melstage2_golden.npz"

@@ -110,6 +110,7 @@ CASES = {
     "hinge_thaw": (dict(stage_name="stage2", epochs=2, gan_loss="hinge", d_step_period=2, disc_use_content_cond=True, adaptive_content_weight=True,
                         adaptive_conf_low=0.9, adaptive_conf_high=0.95, d_loss_floor_for_step=0.2, style_thaw_last_epochs=1,
                         style_thaw_scope="shared_style", style_thaw_lr=1e-3, style_lowpass_cutoff_hz=6000.0, **_BINS), 2, [0, 1, 2]),
+    "bce_r1": (dict(stage_name="stage2", epochs=1, gan_loss="bce", r1_gamma=1.5, r1_interval=2, d_loss_floor_for_step=0.5, **_BINS), 3, [0, 1, 2]),
 }
 
 

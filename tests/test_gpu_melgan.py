@@ -238,6 +238,3 @@ def test_train_stage1_runs_checkpoints_and_resumes(tmp_path):
     assert PT.train_stage1(G, D, enc, batches, cond_bank, DEV, cfg, ckpt, resume=True) == []
     with pytest.raises(ValueError):  # content weight without an encoder is an error, not a silent drop
         PT.train_stage1(G, D, None, batches, cond_bank, DEV, cfg, tmp_path / "x.pt")
-    with pytest.raises(NotImplementedError):
-        PT.mel_stage1_iteration(PT.StageTrainConfig(stage_name="s", epochs=1, r1_gamma=1.0), G, D, None, None, batches[0]["mel_norm"].to(DEV),
-                                batches[0]["z_content"].to(DEV), cond_bank[:1].expand(4, 8).to(DEV), 0)

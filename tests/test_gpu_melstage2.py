@@ -67,13 +67,13 @@ def test_train_stage2_follows_the_reference_run(case, tmp_path, monkeypatch):
             if k in ("epoch", "d_steps_taken", "d_steps_skipped", "d_step_rate", "content_weight", "lr_g", "style_thaw_active", "cond_alpha"):
                 assert abs(v - want) <= 1e-9 + 1e-6 * abs(want), (case, e, k, v, want)
                 continue
-            rtol = {("all_terms", 1): 2e-5, ("all_terms", 2): 1e-2, ("all_terms", 3): 1e-2, ("hinge_thaw", 1): 5e-3, ("hinge_thaw", 2): 3e-2}[(case, e)]
+            rtol = {("all_terms", 1): 2e-5, ("all_terms", 2): 1e-2, ("all_terms", 3): 1e-2, ("hinge_thaw", 1): 5e-3, ("hinge_thaw", 2): 3e-2, ("bce_r1", 1): 1e-2}[(case, e)]
             err = abs(v - want)
             worst[(e, k)] = err / max(abs(want), 1e-3)
             assert err <= rtol * abs(want) + (2e-6 if rtol < 1e-4 else 2e-4), (case, e, k, v, want)
     print(case, "worst relative deviation per epoch:", {e: max(v for (ee, _), v in worst.items() if ee == e) for e in {ee for ee, _ in worst}})
     assert sorted(payload.keys()) == GOLD[f"stage2/{case}/ckpt/keys"].tolist()
-    n_steps = sum(1 for _ in hist) * (1 if case == "all_terms" else 2)
+    n_steps = {"all_terms": 3, "hinge_thaw": 4, "bce_r1": 3}[case]
     for group, lr in (("generator", cfg.lr_g), ("discriminator", cfg.lr_d), ("style_critic", cfg.style_critic_lr),
                       ("frozen_encoder_model", cfg.style_thaw_lr)):
         for k, v in payload[group].items():
@@ -94,10 +94,7 @@ def test_train_stage2_follows_the_reference_run(case, tmp_path, monkeypatch):
         assert moved["shared.weight"] > 0 and moved["style_head.weight"] > 0 and moved["content_head.weight"] == 0 and moved["backbone.0.weight"] == 0
 
 
-def test_stage2_refuses_what_it_does_not_implement(tmp_path):
-    cfg = PT.StageTrainConfig(stage_name="stage2", epochs=1, r1_gamma=1.0)
-    with pytest.raises(NotImplementedError):
-        PT.train_stage2(None, None, None, [], torch.zeros(2, 4), torch.zeros(2, 4), None, None, DEV, cfg, tmp_path / "x.pt")
+def test_stage2_rejects_an_unknown_thaw_scope(tmp_path):
     G = PM.ReconstructionDecoder(**C.G_KW).to(DEV)
     D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM).to(DEV)
     cfg = PT.StageTrainConfig(stage_name="stage2", epochs=1, style_thaw_scope="everything")
@@ -139,3 +136,54 @@ def test_spectral_norm_modules_match_the_reference():
     with torch.no_grad():
         fp_close(G(zc, v), GOLD["sn/eval/g_out_fp"], "eval decoder", rtol=1e-4)
         close(D(mel_in, v).cpu().numpy(), GOLD["sn/eval/d_logit"], atol=2e-6, what="eval logit")
+
+
+def test_r1_penalty_matches_the_reference():
+    """_r1_penalty (reference lab3_train.py:329-339): the discriminator's convolutions as twice-differentiable nodes (ops.ConvTwice), the
+    penalty's value, its gradient with respect to every parameter and the BatchNorm buffers against the reference's double backward."""
+    from oracle.procfill import proc_input
+    from test_gpu_melgan import close, fp_close
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=8)
+    D.load_state_dict(fill_state_dict(D.state_dict(), 52))
+    D = D.to(DEV).train()
+    real = proc_input((4, 32, 64), "melr1.real", 0, 0.8).to(DEV)
+    cond = proc_input((4, 8), "melr1.cond", 0).to(DEV)
+    pen = PT._r1_penalty(D, real, cond)
+    close(float(pen.detach()), GOLD["r1/penalty"], rtol=2e-4, what="penalty")
+    grads = torch.autograd.grad(0.5 * 2.0 * pen, list(D.parameters()), allow_unused=True)
+    for (n, p), g in zip(D.named_parameters(), grads):
+        want = GOLD[f"r1/grad/{n}"]
+        if g is None:
+            assert want[1] == 0.0, (n, "the reference has a gradient here")
+            continue
+        fp_close(g, want, f"R1 gradient {n}", rtol=1e-3)
+    for n, b in D.named_buffers():
+        if b.is_floating_point():
+            close(b.cpu().numpy(), GOLD[f"r1/buf/{n}"], rtol=1e-4, atol=1e-6, what=n)
+    MS = PM.MultiScaleMelDiscriminator(cond_dim=8, base_channels=16)
+    MS.load_state_dict(fill_state_dict(MS.state_dict(), 53))
+    pen_ms = PT._r1_penalty(MS.to(DEV).train(), proc_input((2, 64, 128), "melr1.real_ms", 0, 0.8).to(DEV), cond[:2])
+    close(float(pen_ms.detach()), GOLD["r1/multiscale_penalty"], rtol=2e-4, what="multi-scale penalty")
+
+
+def test_train_stage1_with_r1_follows_the_reference_run(tmp_path):
+    G = PM.ReconstructionDecoder(**C.G_KW)
+    G.load_state_dict(fill_state_dict(G.state_dict(), 21))
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM)
+    D.load_state_dict(fill_state_dict(D.state_dict(), 22))
+    G, D = G.to(DEV), D.to(DEV)
+    cfg = PT.StageTrainConfig(stage_name="stage1", epochs=2, max_batches_per_epoch=1, gan_loss="hinge", r1_gamma=2.0, r1_interval=2,
+                              weights=PT.TrainWeights(content=0.0, style=0.0), mrstft_resolutions=((16, 4, 16), (32, 8, 32), (64, 16, 64)))
+    cond_bank, _, _ = C.stage2_banks()
+    hist = PT.train_stage1(G, D, C.ToyFrozenEncoder(DEV), C.ListLoader(C.stage2_batches(1), [0, 1, 2]), cond_bank, DEV, cfg, tmp_path / "s1.pt")
+    assert hist[0]["loss_r1"] > 0.01 and hist[1]["loss_r1"] == 0.0  # R1 on step 0 only (interval 2)
+    for ep in hist:
+        for k, v in ep.items():
+            if k == "stage":
+                continue
+            want = float(GOLD[f"r1/stage1/hist/{ep['epoch']}/{k}"])
+            rtol = 2e-4 if ep["epoch"] == 1 else 1e-2
+            assert abs(v - want) <= rtol * abs(want) + 1e-6, (ep["epoch"], k, v, want)
+    for n, p in D.named_parameters():
+        got, want = fp(p), GOLD[f"r1/stage1/d_param/{n}"]
+        assert np.all(np.abs(got[3:] - want[3:]) <= 2 * 2 * cfg.lr_d + 1e-5), (n, got[3:], want[3:])
