@@ -224,22 +224,39 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def lstm_flag_on_any_rank() -> bool:
+        """The sticky error word of the persistent LSTM launches (read and cleared), OR-ed over the ranks so that all of them take
+        the same branch."""
+        f = 1.0 if ops.lstm_persist_error(device) else 0.0
+        if dp is not None:
+            t = torch.tensor([f], device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            f = float(t)
+        return f > 0.0
+
     def measure(batch, steps=None, warmup=None):
-        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+        If a persistent LSTM launch ran out of its bounded wait while gradient all-reduces were overlapped with the backward pass
+        (RCCL kernels beside a kernel that needs a workgroup on every CU: never run on hardware before this bench, gan_amd/dp.py),
+        every rank drops to the after-backward all-reduce and the measurement is taken again; the line then says so."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
         state["batches"] = [make_batch(batch, args.frames, device, gen) for _ in range(2)]
-        for _ in range(warmup):
-            out = step()
-            if dp is not None:
-                dp.check_first_overlapped_iteration(device)  # (once: RCCL kernels beside the persistent LSTM, gan_amd/dp.py)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = step()
-        barrier()
-        el = time.perf_counter() - t0
-        if ops.lstm_persist_error(device):  # sticky: any persistent LSTM launch since the last look
+        for attempt in (0, 1):
+            for _ in range(warmup):
+                out = step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = step()
+            barrier()
+            el = time.perf_counter() - t0
+            if not lstm_flag_on_any_rank():
+                break
+            if attempt == 0 and dp is not None and dp.overlap:
+                dp.overlap = False
+                state["overlap_fallback"] = True
+                continue
             raise SystemExit("a persistent LSTM launch of the frozen decoder ran out of its bounded wait: the timed steps are invalid")
         if dp is not None:
             t = torch.tensor([el], device=device, dtype=torch.float64)
@@ -368,6 +385,10 @@ def main():
             line["fp32_batch12"] = fp32_b12
         if stage2 is not None:
             line["stage2_like"] = stage2
+        if dp is not None:
+            line["config"]["dp_allreduce"] = ("overlapped with the backward pass" if dp.overlap else
+                                              "after the backward pass" + (" (fell back: a persistent LSTM launch lost its residency beside the "
+                                                                           "overlapped collectives)" if state.get("overlap_fallback") else ""))
         line["config"]["note"] = ("headline batch is 64 per GPU since round 2 (round 1's BENCH line was B=12): compare rounds on "
                                   "'batch12', the reference's default batch, which every run reports")
         if world == 1 and not args.no_cpu_baseline:
