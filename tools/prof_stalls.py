@@ -14,8 +14,12 @@ res = []
 for s, e, q, _ in lstm:
     inside = [(r[1] - r[0]) / 1e3 for r in rows if r[2] != q and s <= r[0] < e and "conv_gemm_kernel" in r[3]]
     first = min([(r[0] - s) / 1e3 for r in rows if r[2] != q and s <= r[0] < e and "conv_gemm_kernel" in r[3]], default=-1)
-    res.append(((e - s) / 1e3, len(inside), max(inside, default=0.0), first))
-for d, n, mx, first in res:
-    print(f"LSTM {d:7.1f} us: {n:3d} convs started inside it, longest {mx:7.1f} us, first one {first:6.1f} us after the LSTM's start")
-bad = sum(1 for _, _, mx, _ in res if mx > 1000)
-print(f"{bad} of {len(res)} LSTM launches caught a conv for more than 1 ms")
+    # a conv on the other queue that overlaps the LSTM launch for more than 1.5 ms was caught by it, wherever it started
+    caught = [((r[0] - s) / 1e3, (r[1] - r[0]) / 1e3) for r in rows if r[2] != q and "conv_gemm_kernel" in r[3] and r[0] < e and r[1] > s
+              and (min(r[1], e) - max(r[0], s)) > 1.5e6]
+    res.append(((e - s) / 1e3, len(inside), max(inside, default=0.0), first, caught))
+for d, n, mx, first, caught in res:
+    c = "; CAUGHT: conv started %+.1f us from the LSTM's start, ran %.0f us" % caught[0] if caught else ""
+    print(f"LSTM {d:7.1f} us: {n:3d} convs started inside it, longest {mx:7.1f} us, first one {first:6.1f} us after the LSTM's start{c}")
+bad = sum(1 for r in res if r[4])
+print(f"{bad} of {len(res)} LSTM launches held a conv of the other queue for more than 1.5 ms")
