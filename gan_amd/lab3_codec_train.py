@@ -263,6 +263,7 @@ ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "32"))
 # High priority for the side stream: when the persistent LSTM launch and a generator conv are dispatched within ~20 us of each other,
 # the conv can be held for the LSTM's whole 2.2 ms ("dispatch-window stall"); with the LSTM's queue served first that
 # happened in 5 of 42 steps instead of 13, and four interleaved A/B pairs gave 47.07 +- 0.03 ms against 47.27 +- 0.15.
+BUDGET_THROUGH_PRE_LSTM = os.environ.get("GA_BUDGET_PRE_LSTM", "1") == "1"
 SIDE_STREAM_PRIORITY = int(os.environ.get("GA_SIDE_PRIO", "-1"))
 ASYNC_GEMM_LDS_BUDGET = int(os.environ.get("GA_ASYNC_GEMM_LDS", str(25 * 1024)))  # 0: the generator's convs keep their usual tiles
 
@@ -314,14 +315,19 @@ def codec_train_iteration(stage_cfg: CodecStageTrainConfig, generator: CodecLate
         # The side stream's LSTM launch holds one workgroup with 111-137 KiB of LDS on every CU for ~2 ms; the generator's small
         # convolutions share the CUs with it when their workgroups fit into what is left (24 KiB tiles), instead of queueing
         # behind it (rocprofv3 timeline: the generator's first conv waited 2.2 ms for the LSTM to leave).
-        prev_budget = L.lib().ga_set_gemm_lds_budget(ASYNC_GEMM_LDS_BUDGET) if ASYNC_GEMM_LDS_BUDGET > 0 else None
+        # The budget stays in force through the first conv and the LSTM input projection of the decode of q_hat: they too would
+        # otherwise wait for the side stream's LSTM to leave (1.1 ms of idle main stream in the timeline), and end right before this
+        # decode's own LSTM launch (ops.LstmSkip lifts it), which has to wait for the other one in any case.
+        if ASYNC_GEMM_LDS_BUDGET > 0:
+            ops.hold_gemm_lds_budget(ASYNC_GEMM_LDS_BUDGET)
         try:
             q_hat = generator(q_src=q_src, z_content=zc_src, z_style_tgt=z_style_tgt, noise=noise,
                               style_dropout_p=float(stage_cfg.style_dropout_p), style_jitter_std=float(stage_cfg.style_jitter_std))
+            if not BUDGET_THROUGH_PRE_LSTM:
+                ops.lift_gemm_lds_budget()
+            x_hat = codec.decode_embeddings(q_hat)
         finally:
-            if prev_budget is not None:
-                L.lib().ga_set_gemm_lds_budget(prev_budget)
-        x_hat = codec.decode_embeddings(q_hat)
+            ops.lift_gemm_lds_budget()
         main.wait_stream(side)
         frozen_out.record_stream(main)
     else:

@@ -1686,6 +1686,25 @@ def lstm_persist_error(device=None, clear: bool = True) -> bool:
     return hit
 
 
+_BUDGET_TO_RESTORE: Optional[int] = None  # the LDS budget that was in force before hold_gemm_lds_budget()
+
+
+def hold_gemm_lds_budget(nbytes: int) -> None:
+    """Gathered GEMMs launched from here on take tiles of at most `nbytes` of LDS (ga_set_gemm_lds_budget) until
+    lift_gemm_lds_budget() -- which the next LSTM forward launch calls by itself, so that the budget covers exactly the convolutions
+    issued while ANOTHER stream's persistent LSTM launch owns most of every CU's LDS."""
+    global _BUDGET_TO_RESTORE
+    if _BUDGET_TO_RESTORE is None:
+        _BUDGET_TO_RESTORE = int(L.lib().ga_set_gemm_lds_budget(int(nbytes)))
+
+
+def lift_gemm_lds_budget() -> None:
+    global _BUDGET_TO_RESTORE
+    if _BUDGET_TO_RESTORE is not None:
+        L.lib().ga_set_gemm_lds_budget(_BUDGET_TO_RESTORE)
+        _BUDGET_TO_RESTORE = None
+
+
 class LstmSkip(torch.autograd.Function):
     """y = LSTM2(x) + x for the frozen decoder (HF EncodecLSTM); x, y: [B, T, H] channels-last.
     `w` is the dict prepared by prepare_lstm_weights (frozen, cached by the decoder)."""
@@ -1721,6 +1740,7 @@ class LstmSkip(torch.autograd.Function):
               gates1=L.ptr(gates[0]) if need_grad else 0, gates2=L.ptr(gates[1]) if need_grad else 0,
               cs1=L.ptr(cs[0]) if need_grad else 0, cs2=L.ptr(cs[1]) if need_grad else 0, B=B, T=T, H=H,
               act_dtype=L.dt(x), w_dtype=L.dt(h1), B_save=Bg)
+        lift_gemm_lds_budget()  # (a caller's budget covers the convs in FRONT of the LSTM launch only)
         L.check(L.lib().ga_lstm_fwd(C.byref(p), L.stream()), "ga_lstm_fwd")
         if need_grad:
             ctx.save_for_backward(gates, cs)
