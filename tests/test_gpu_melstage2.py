@@ -187,3 +187,40 @@ def test_train_stage1_with_r1_follows_the_reference_run(tmp_path):
     for n, p in D.named_parameters():
         got, want = fp(p), GOLD[f"r1/stage1/d_param/{n}"]
         assert np.all(np.abs(got[3:] - want[3:]) <= 2 * 2 * cfg.lr_d + 1e-5), (n, got[3:], want[3:])
+
+
+def test_bf16_mode_r1_and_stage2_stay_close_to_fp32(tmp_path, monkeypatch):
+    """precision="bf16" (bf16 MFMA operands, fp32 accumulation and parameters): the R1 penalty through the twice-differentiable nodes
+    within 5 % of the fp32-mode value with parameter-gradient cosine >= 0.98, and a stage-2 run whose first-iteration loss columns stay
+    within 3e-2 (absolute, on O(1) quantities) of the reference fixture."""
+    from oracle.procfill import proc_input
+    real = proc_input((4, 32, 64), "melr1.real", 0, 0.8).to(DEV)
+    cond = proc_input((4, 8), "melr1.cond", 0).to(DEV)
+    pens, grads = {}, {}
+    for prec in ("fp32", "bf16"):
+        D = PM.MelDiscriminator(base_channels=16, cond_dim=8, precision=prec)
+        D.load_state_dict(fill_state_dict(D.state_dict(), 52))
+        D = D.to(DEV).train()
+        pen = PT._r1_penalty(D, real, cond)
+        g = torch.autograd.grad(pen, [p for p in D.parameters()], allow_unused=True)
+        pens[prec] = float(pen.detach())
+        grads[prec] = torch.cat([x.reshape(-1).float() for x in g if x is not None])
+    assert abs(pens["bf16"] - pens["fp32"]) <= 0.05 * abs(pens["fp32"]), pens
+    cos = float(torch.nn.functional.cosine_similarity(grads["bf16"], grads["fp32"], dim=0))
+    assert cos >= 0.98, cos
+    kw, _, _ = C.CASES["all_terms"]
+    G = PM.ReconstructionDecoder(precision="bf16", **C.G_KW)
+    G.load_state_dict(fill_state_dict(G.state_dict(), 21))
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM, precision="bf16")
+    D.load_state_dict(fill_state_dict(D.state_dict(), 22))
+    cond_bank, proto, prof = C.stage2_banks()
+    cfg = PT.StageTrainConfig(weights=PT.TrainWeights(**C.ALL_WEIGHTS), **kw)
+    monkeypatch.setattr(PT, "StyleCritic", lambda **k: PM.StyleCritic(dropout=0.0, **k))
+    torch.manual_seed(C.STAGE2_SEED)
+    hist = PT.train_stage2(G.to(DEV), D.to(DEV), C.ToyFrozenEncoder(DEV), C.loader_for("all_terms"), cond_bank, proto, None, prof, DEV, cfg,
+                           tmp_path / "s2.pt")
+    worst = 0.0
+    for k in PT.STAGE2_KEYS:
+        want = float(GOLD[f"stage2/all_terms/hist/1/{k}"])
+        worst = max(worst, abs(hist[0][k] - want) / max(1.0, abs(want)))
+    assert worst <= 3e-2, worst
