@@ -651,7 +651,10 @@ int ga_thin_wgrad_supported(const WgradParams& p, int dtype) {
     if (p.Cin == 1 && p.M % 8 == 0 && p.M <= 256 && p.J <= 16 && p.in_stride >= 1 && p.in_stride <= 4 &&
         (p.J - 1) * p.tap_step < 64 && aligned16(p.g) && (p.M * esz) % 16 == 0)
         return 1;
-    if (p.M == 1 && p.Cin % 8 == 0 && p.Cin <= 2048 && 256 % (p.Cin / 8) == 0 && p.J <= 8 && p.in_stride >= 1 && aligned16(p.x) && (p.Cin * esz) % 16 == 0)
+    // (the row-walking kernel below takes any multiple of 32 channels at stride 1; the one-row-per-lane-group kernel needs the row's
+    // 16-byte pieces to divide a workgroup)
+    if (p.M == 1 && p.Cin % 8 == 0 && p.Cin <= 2048 && (256 % (p.Cin / 8) == 0 || (p.Cin % 32 == 0 && p.in_stride == 1)) && p.J <= 8 &&
+        p.in_stride >= 1 && aligned16(p.x) && (p.Cin * esz) % 16 == 0)
         return 2;
     return 0;
 }
@@ -732,9 +735,13 @@ static int thin_wgrad_t(const WgradParams& p, float* dbias, int kind, hipStream_
         const int chunks_per_b = (p.Lout + WG1_ROWS - 1) / WG1_ROWS;
         wgrad_cin1_kernel<T><<<p.B * chunks_per_b, 256, 0, s>>>(p, dbias, chunks_per_b);
     } else {
-        if (p.Cin >= 256 && p.Cin % 32 == 0 && p.in_stride == 1 && (long)p.B * p.Lin < (1L << 30)) {
+        // wide inputs, and narrower ones with very many rows (the mel decoder's last conv: 96 gathered channels x 1.5M rows, where
+        // the kernel below it took 4.4 ms for one pass over 300 MB) or with a piece count that does not divide a workgroup
+        const bool many_rows = (long)p.B * p.Lin >= (1L << 16) || 256 % (p.Cin / 8) != 0;
+        if ((p.Cin >= 256 || many_rows) && p.Cin % 32 == 0 && p.in_stride == 1 && (long)p.B * p.Lin < (1L << 30)) {
             long ny = ((long)p.B * p.Lin + 1023) / 1024;  // >= 4 trips of 256 rows per workgroup
-            if (ny > 32) ny = 32;
+            const long cap = p.Cin >= 256 ? 32 : 1536 / (p.Cin / 32);  // ~1-1.5k workgroups in all
+            if (ny > cap) ny = cap;
             if (ny < 1) ny = 1;
             wgrad_m1_wide_kernel<T><<<dim3(p.Cin / 32, (unsigned)ny), 256, 0, s>>>(p, dbias);
             GA_CHECK_LAUNCH();

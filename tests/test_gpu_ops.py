@@ -59,6 +59,7 @@ TRAIN_CASES = [
     (ConvGeom("conv", 1, 32, 15, 1, 7, 1), 6001, True, L.ACT_LRELU),
     (ConvGeom("conv", 64, 1, 3, 1, 1, 1), 5003, True, L.ACT_NONE),
     (ConvGeom("conv", 512, 1, 3, 1, 1, 1), 4100, True, L.ACT_NONE),
+    (ConvGeom("conv", 96, 1, 3, 1, 1, 1), 30011, False, L.ACT_NONE),        # the mel decoder's last conv after the row gather: 12 pieces per row, many rows
 ]
 
 
