@@ -130,6 +130,8 @@ _SIGNATURES = {
     "ga_avgpool1d_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "ga_act_bwd": [_P, _P, _P, _I, _Z, _I, _P],
     "ga_act_fwd": [_P, _P, _I, _Z, _I, _P],
+    "ga_rowgather_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_rowgather_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_act_bwd_bias": [_P, _P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_colsum": [_P, _I, _Z, _I, _P, _P],
     "ga_reduce": [_P, _P, _I, _Z, _I, _F, _P, _P],

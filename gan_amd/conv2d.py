@@ -32,6 +32,39 @@ def to_nchw_view(y_nhwc: torch.Tensor) -> torch.Tensor:
     return y_nhwc.permute(0, 3, 1, 2)
 
 
+class RowGather(torch.autograd.Function):
+    """xr[b, oh, w, i*C + c] = x[b, s*oh + i - p, w, c] (zero rows for the padding, zero channels up to kc8): one launch forward
+    (ga_rowgather_fwd), one backward (its adjoint) -- as tensor ops this was a pad, kh strided slices and a concatenation, and in
+    the backward pass a zero fill, a copy and an add per kernel row.  Linear, so its own backward is differentiable again (R1)."""
+
+    @staticmethod
+    def forward(ctx, x, kh: int, s: int, p: int, OH: int, kc8: int):
+        B, H, W, C = x.shape
+        y = torch.empty((B, OH, W, kc8), device=x.device, dtype=x.dtype)
+        L.check(L.lib().ga_rowgather_fwd(x.data_ptr(), y.data_ptr(), L.dt(x), B, H, W, C, kh, s, p, OH, kc8, L.stream()), "ga_rowgather_fwd")
+        ctx.geom = (B, H, W, C, kh, s, p, OH, kc8)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _RowScatter.apply(gy.contiguous(), ctx.geom), None, None, None, None, None
+
+
+class _RowScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, geom):
+        B, H, W, C, kh, s, p, OH, kc8 = geom
+        gx = torch.empty((B, H, W, C), device=gy.device, dtype=gy.dtype)
+        L.check(L.lib().ga_rowgather_bwd(gy.data_ptr(), gx.data_ptr(), L.dt(gy), B, H, W, C, kh, s, p, OH, kc8, L.stream()), "ga_rowgather_bwd")
+        ctx.geom = geom
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        B, H, W, C, kh, s, p, OH, kc8 = ctx.geom
+        return RowGather.apply(ggx.contiguous(), kh, s, p, OH, kc8), None
+
+
 TWICE_DIFFERENTIABLE = False  # set by `twice_differentiable()`: convolutions become ops.ConvTwice nodes (gradient penalties)
 
 
@@ -59,14 +92,9 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     OH = (H + 2 * p - kh) // s + 1
     if OH < 1 or (W + 2 * p - kw) // s + 1 < 1:
         raise ValueError("convolution window larger than the padded input")
-    xp = F.pad(x, (0, 0, 0, 0, p, p)) if p else x  # zero rows above and below
-    last = s * (OH - 1) + 1
-    rows = [xp[:, i:i + last:s] for i in range(kh)]
     kc = kh * C
     kc8 = (kc + 7) // 8 * 8  # the GEMM kernels stage 16-byte (8-channel) pieces
-    if kc8 != kc:
-        rows.append(x.new_zeros(B, OH, W, kc8 - kc))
-    xr = torch.cat(rows, dim=-1) if len(rows) > 1 else rows[0].contiguous()
+    xr = RowGather.apply(x.contiguous(), kh, s, p, OH, kc8)
     w1 = weight.permute(0, 2, 1, 3).reshape(M, kc, kw)  # [m, (i, c), j]
     if kc8 != kc:
         w1 = F.pad(w1, (0, 0, 0, kc8 - kc))
@@ -83,6 +111,14 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 #   phi = 0: x[t-1] * w[3] + x[t] * w[1]        phi = 1: x[t] * w[2] + x[t+1] * w[0]
 # i.e. a 3-tap convolution (offsets -1, 0, +1) whose taps are a subset of the 4-tap kernel: {tap: kernel index} per phase.
 _TAPS = ({0: 3, 1: 1}, {1: 2, 2: 0})
+_TAP_INDEX = {}
+
+
+def _tap_index(device) -> torch.Tensor:
+    t = _TAP_INDEX.get(device)
+    if t is None:
+        t = _TAP_INDEX[device] = torch.tensor([[_TAPS[ph].get(a, 4) for a in range(3)] for ph in (0, 1)], device=device)
+    return t
 
 
 def conv_transpose2d_k4s2p1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], post_act: int = L.ACT_NONE) -> torch.Tensor:
@@ -93,13 +129,12 @@ def conv_transpose2d_k4s2p1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Op
     C, M = weight.shape[0], weight.shape[1]
     if tuple(weight.shape[2:]) != (4, 4):
         raise ValueError("kernel 4 x 4 expected")
-    w3 = weight.new_zeros(M, 2, 2, C, 3, 3)
-    for ph in (0, 1):
-        for a, ih in _TAPS[ph].items():
-            for pw in (0, 1):
-                for b, iw in _TAPS[pw].items():
-                    w3[:, ph, pw, :, a, b] = weight[:, :, ih, iw].t()
+    # one gather instead of 16 slice assignments (and as many again in the backward pass): kernel index 4 is a zero row / column
+    wp = F.pad(weight, (0, 1, 0, 1))                                         # [C, M, 5, 5]
+    idx = _tap_index(weight.device)                                          # [phase][tap] -> kernel index
+    w3 = wp[:, :, idx[:, :, None, None], idx[None, None, :, :]]              # [C, M, ph, a, pw, b]
+    w3 = w3.permute(1, 2, 4, 0, 3, 5)                                        # [M, ph, pw, C, a, b]
     b4 = None if bias is None else bias.repeat_interleave(4)
-    y = conv2d_nhwc(x, w3.view(4 * M, C, 3, 3), b4, 1, 1, post_act)  # [B, H, W, (m, ph, pw)]
+    y = conv2d_nhwc(x, w3.reshape(4 * M, C, 3, 3), b4, 1, 1, post_act)  # [B, H, W, (m, ph, pw)]
     B, H, W, _ = y.shape
     return y.view(B, H, W, M, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, M)

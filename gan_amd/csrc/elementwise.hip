@@ -1075,6 +1075,79 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 // C ABI
 int ga_colsum_vec_supported(const void* g, int dtype, int M);
 int ga_colsum_vec_impl(const void* g, int dtype, size_t rows, int M, float* out, hipStream_t s);
+// ================================================================================================
+// 2-D convolutions as 1-D implicit GEMMs (gan_amd/conv2d.py): the kernel ROWS of a channels-last image gathered into the channel axis.
+//   y[b][oh][w][i*C + c] = x[b][S*oh + i - P][w][c]   (zero outside the image; channels KH*C .. KC-1 of y are zero padding)
+// and the adjoint  gx[b][h][w][c] = sum_{i : (h + P - i) % S == 0, oh = (h + P - i) / S < OH} gy[b][oh][w][i*C + c].
+// One thread per 16-byte piece when C is a multiple of the piece, per element otherwise (the discriminator's one-channel input).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void rowgather_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int KH, int S,
+                                                            int P, int OH, int KC) {
+    constexpr int EV = VEC ? 16 / (int)sizeof(T) : 1;
+    const int kcv = KC / EV, cv = C / EV;
+    const size_t total = (size_t)B * OH * W * kcv;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % kcv);
+        size_t r = idx / kcv;
+        const int w = (int)(r % W);
+        r /= W;
+        const int oh = (int)(r % OH), b = (int)(r / OH);
+        const int i = k / cv, c = (k - i * cv) * EV;
+        const int h = S * oh + i - P;
+        const bool ok = i < KH && h >= 0 && h < H;
+        if (VEC) {
+            Pack16<T> v;
+            if (ok) v = *(const Pack16<T>*)(x + (((size_t)b * H + h) * W + w) * C + c);
+            else
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v.v[e] = (T)0.f;
+            *(Pack16<T>*)(y + idx * EV) = v;
+        } else {
+            y[idx] = ok ? x[(((size_t)b * H + h) * W + w) * C + c] : (T)0.f;
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void rowgather_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int H, int W, int C, int KH, int S,
+                                                            int P, int OH, int KC) {
+    constexpr int EV = VEC ? 16 / (int)sizeof(T) : 1;
+    const int cv = C / EV;
+    const size_t total = (size_t)B * H * W * cv;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * EV;
+        size_t r = idx / cv;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H), b = (int)(r / H);
+        float acc[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) acc[e] = 0.f;
+        for (int i = 0; i < KH; ++i) {
+            const int t = h + P - i;
+            if (t < 0 || t % S) continue;
+            const int oh = t / S;
+            if (oh >= OH) continue;
+            const T* src = gy + (((size_t)b * OH + oh) * W + w) * KC + (size_t)i * C + c;
+            if (VEC) {
+                const Pack16<T> v = *(const Pack16<T>*)src;
+#pragma unroll
+                for (int e = 0; e < EV; ++e) acc[e] += (float)v.v[e];
+            } else {
+                acc[0] += (float)src[0];
+            }
+        }
+        if (VEC) {
+            Pack16<T> o;
+#pragma unroll
+            for (int e = 0; e < EV; ++e) o.v[e] = (T)acc[e];
+            *(Pack16<T>*)(gx + idx * EV) = o;
+        } else {
+            gx[idx] = (T)acc[0];
+        }
+    }
+}
+
 static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
     size_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -1255,6 +1328,47 @@ int ga_act_bwd_bias(const void* gy, const void* src, void* ga, int dtype, size_t
     const int grid = grid_for(nv, 256, 2048);
     DISPATCH_T(dtype, (act_bwd_bias_kernel<float><<<grid, 256, 0, s>>>((const float*)gy, (const float*)src, (float*)ga, nv, mode, M, dbias)),
                (act_bwd_bias_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)gy, (const bf16_t*)src, (bf16_t*)ga, nv, mode, M, dbias)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+static int rowgather_check(const void* a, const void* b, int dtype, int B, int H, int W, int C, int KH, int S, int P, int OH, int KC) {
+    if (!a || !b || (dtype != GA_DTYPE_F32 && dtype != GA_DTYPE_BF16)) return GA_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || S <= 0 || P < 0 || OH <= 0 || KC < KH * C) return GA_ERR_ARG;
+    if ((long)S * (OH - 1) - P + (KH - 1) >= (long)H + P) return GA_ERR_ARG;  // the last window reaches past the padded image
+    return GA_OK;
+}
+int ga_rowgather_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C, int KH, int S, int P, int OH, int KC, hipStream_t s) {
+    const int rc = rowgather_check(x, y, dtype, B, H, W, C, KH, S, P, OH, KC);
+    if (rc) return rc;
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    const bool vec = C % ev == 0 && KC % ev == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    const size_t work = (size_t)B * OH * W * (vec ? KC / ev : KC);
+    const int grid = grid_for(work, 256, 8192);
+    if (vec) {
+        DISPATCH_T(dtype, (rowgather_fwd_kernel<float, true><<<grid, 256, 0, s>>>((const float*)x, (float*)y, B, H, W, C, KH, S, P, OH, KC)),
+                   (rowgather_fwd_kernel<bf16_t, true><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, B, H, W, C, KH, S, P, OH, KC)));
+    } else {
+        DISPATCH_T(dtype, (rowgather_fwd_kernel<float, false><<<grid, 256, 0, s>>>((const float*)x, (float*)y, B, H, W, C, KH, S, P, OH, KC)),
+                   (rowgather_fwd_kernel<bf16_t, false><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, B, H, W, C, KH, S, P, OH, KC)));
+    }
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_rowgather_bwd(const void* gy, void* gx, int dtype, int B, int H, int W, int C, int KH, int S, int P, int OH, int KC, hipStream_t s) {
+    const int rc = rowgather_check(gy, gx, dtype, B, H, W, C, KH, S, P, OH, KC);
+    if (rc) return rc;
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    const bool vec = C % ev == 0 && KC % ev == 0 && ((((uintptr_t)gy | (uintptr_t)gx) & 15) == 0);
+    const size_t work = (size_t)B * H * W * (vec ? C / ev : C);
+    const int grid = grid_for(work, 256, 8192);
+    if (vec) {
+        DISPATCH_T(dtype, (rowgather_bwd_kernel<float, true><<<grid, 256, 0, s>>>((const float*)gy, (float*)gx, B, H, W, C, KH, S, P, OH, KC)),
+                   (rowgather_bwd_kernel<bf16_t, true><<<grid, 256, 0, s>>>((const bf16_t*)gy, (bf16_t*)gx, B, H, W, C, KH, S, P, OH, KC)));
+    } else {
+        DISPATCH_T(dtype, (rowgather_bwd_kernel<float, false><<<grid, 256, 0, s>>>((const float*)gy, (float*)gx, B, H, W, C, KH, S, P, OH, KC)),
+                   (rowgather_bwd_kernel<bf16_t, false><<<grid, 256, 0, s>>>((const bf16_t*)gy, (bf16_t*)gx, B, H, W, C, KH, S, P, OH, KC)));
+    }
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -375,6 +375,12 @@ int ga_act_bwd_bias(const void* gy, const void* src, void* ga, int dtype, size_t
 /* y = act(x), elementwise (GA_ACT_*): the ELU in front of every SEANet decoder conv (modeling_encodec.py:265-275,
  * 330-343), materialised once so that the conv itself can stream its operand straight into LDS */
 int ga_act_fwd(const void* x, void* y, int dtype, size_t n, int act, ga_stream_t stream);
+/* nn.Conv2d / nn.ConvTranspose2d of the mel track (lab 3/src/lab3_models.py:22-27,88,95,101,114,156-164) run as 1-D implicit GEMMs along W
+ * after the KH kernel rows of a channels-last image [B][H][W][C] have been gathered into the channel axis:
+ *   y[b][oh][w][i*C + c] = x[b][S*oh + i - P][w][c], zero outside the image and in the padding channels KH*C .. KC-1   (y: [B][OH][W][KC])
+ * ga_rowgather_bwd is the adjoint (gx[b][h][w][c] = sum of the gy entries that read it).  16-byte pieces when C and KC allow. */
+int ga_rowgather_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C, int KH, int S, int P, int OH, int KC, ga_stream_t stream);
+int ga_rowgather_bwd(const void* gy, void* gx, int dtype, int B, int H, int W, int C, int KH, int S, int P, int OH, int KC, ga_stream_t stream);
 /* out[m] += sum_rows g[row][m]: bias gradient of conv1d (atomics; caller zeroes) */
 int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, ga_stream_t stream);
 
