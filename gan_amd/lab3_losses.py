@@ -37,7 +37,9 @@ def multi_resolution_stft_loss(mel_pred: torch.Tensor, mel_true: torch.Tensor,
         n_fft, hop, win = int(n_fft), int(hop), int(win)
         if t < n_fft:
             continue
-        sums = ops.StftSums.apply(x, y, n_fft, hop, win, precision == "bf16", True)
+        # (the split-bf16 GEMM stages 16-byte pieces of the 3 x hop framed channels and its data gradient has hop output channels:
+        # hops below 16 or not a multiple of 8 -- toy sizes -- take the exact fp32 kernel)
+        sums = ops.StftSums.apply(x, y, n_fft, hop, win, precision == "bf16" and hop >= 16 and hop % 8 == 0, True)
         per_res.append(sums)
         inv_counts.append(1.0 / float(b * n_mels * (n_fft // 2 + 1) * (1 + t // hop)))
     if not per_res:

@@ -280,7 +280,7 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
             p.requires_grad_(r)
     loss_adv = _gan_g_loss(stage_cfg.gan_loss, logit_fake_g, float(stage_cfg.g_real_label), float(stage_cfg.d_fake_label))
     loss_l1 = F.l1_loss(fake, real)
-    loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions)
+    loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions, precision=getattr(generator, "precision", "fp32"))
     loss_mrstft = loss_continuity
     loss_content = loss_style = zero
     if frozen_encoder is not None:
@@ -599,7 +599,7 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
                         + F.mse_loss(F.normalize(fake_zs, dim=-1), F.normalize(enc_ref["z_style"].detach(), dim=-1)))
             loss_infonce = _within_genre_infonce(fake_zs, tgt_idx, float(stage_cfg.batch_infonce_temp))
             loss_l1 = F.l1_loss(fake, real)
-            loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions)
+            loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions, precision=getattr(generator, "precision", "fp32"))
             loss_mrstft = loss_continuity
             loss_lowmid = LL.frequency_weighted_l1_loss(fake, real, split_bin=int(stage_cfg.lowmid_split_bin),
                                                         low_gain=float(stage_cfg.lowmid_gain), high_gain=float(stage_cfg.high_gain))

@@ -1,12 +1,12 @@
 """Mel-track stage-1 iteration time (reference defaults: decoder base 256, discriminator base 64 with the projection head, 96 x 256
-mels, bce loss, adv + L1 + MR-STFT terms) on the HIP-backed modules, fp32 and bf16.  usage: bench_melgan.py [batch]"""
+mels, bce loss, adv + L1 + MR-STFT terms) on the HIP-backed modules, fp32 and bf16.  usage: bench_melgan.py [batch] [fp32|bf16]"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from gan_amd import lab3_models as PM, lab3_train as PT
 from gan_amd.optim import FusedAdamW
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda")
-for prec in ("fp32", "bf16"):
+for prec in ((sys.argv[2],) if len(sys.argv) > 2 else ("fp32", "bf16")):
     torch.manual_seed(0)
     G = PM.ReconstructionDecoder(precision=prec).to(dev).train()
     D = PM.MelDiscriminator(cond_dim=160, precision=prec).to(dev).train()
