@@ -56,3 +56,29 @@ def test_no_cpu_fallback():
     D = PM.MelDiscriminator(base_channels=16)
     with pytest.raises(Exception):
         D(torch.zeros(1, 32, 64))
+
+
+def test_chunk_encoder_layout_and_helpers():
+    """gan_amd.lab3_bridge: the reference ChunkEncoder's parameter names (lab3_bridge.py:37-60), no CPU fallback, and the array helpers."""
+    import numpy as np
+    from gan_amd import lab3_bridge as PB
+    enc = PB.ChunkEncoder(n_sources=4, z_dim=64)
+    keys = list(enc.state_dict())
+    assert keys[:2] == ["backbone.0.weight", "backbone.0.bias"] and "backbone.7.running_var" in keys and "content_style_adv.2.bias" in keys
+    assert tuple(enc.state_dict()["backbone.6.weight"].shape) == (128, 64, 3, 3) and tuple(enc.state_dict()["style_cls.weight"].shape) == (4, 64)
+    with pytest.raises(Exception):
+        enc(torch.zeros(1, 96, 32))
+    db = np.linspace(-100.0, 10.0, 12, dtype=np.float32).reshape(3, 4)
+    n = PB.normalize_log_mel(db)
+    assert n.min() == -1.0 and n.max() == 1.0 and n.dtype == np.float32
+    np.testing.assert_allclose(PB.denormalize_log_mel(torch.from_numpy(n)).numpy(), np.clip(db, -80.0, 0.0), atol=1e-5)
+    assert PB.fix_log_mel_frames(db, 2).tolist() == db[:, 1:3].tolist()
+    padded = PB.fix_log_mel_frames(db, 6)
+    assert padded.shape == (3, 6) and padded[0, 5] == -80.0 and padded[1, 3] == db[1, 3]
+    with pytest.raises(ValueError):
+        PB.fix_log_mel_frames(db[0], 4)
+    d = PB.descriptor32_from_logmel(np.random.default_rng(0).normal(size=(96, 40)).astype(np.float32))
+    assert d.shape == (32,) and abs(float(d.mean())) < 1e-6 and abs(float(d.std()) - 1.0) < 1e-3
+    x = torch.ones(3, requires_grad=True)
+    PB.grad_reverse(x, 0.5).sum().backward()
+    assert x.grad.tolist() == [-0.5, -0.5, -0.5]
