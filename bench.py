@@ -300,6 +300,15 @@ def main():
         el12, _ = measure(12)
         batch12 = {"batch_per_gpu": 12, "global_batch": 12 * world, "value": round(12 * world * args.steps / el12, 3),
                    "unit": "samples/s", "ms_per_step": round(1e3 * el12 / args.steps, 3)}
+    # SURVEY.md 8(d) config 2 sweeps the batch {12, 64, 256, max-fit}: one more point, twice the headline batch (throughput saturates
+    # there: profiles/r03d_batch_sweep.txt), reported under 'batch128' and never mixed into `value`
+    batch128 = None
+    if args.batch == 64 and not args.no_batch12 and not args.stft_stress and args.frames <= 375:
+        n128 = max(2, min(4, args.steps))
+        el128, _ = measure(128, steps=n128, warmup=1)
+        batch128 = {"batch_per_gpu": 128, "global_batch": 128 * world, "value": round(128 * world * n128 / el128, 3), "unit": "samples/s",
+                    "ms_per_step": round(1e3 * el128 / n128, 3), "steps": n128, "warmup": 1}
+        torch.cuda.empty_cache()
     elapsed, loss_g = measure(args.batch)
 
     # per-kernel accounting: one more step with HIP events (torch current stream == launch stream) around every
@@ -381,6 +390,8 @@ def main():
         }
         if batch12 is not None:
             line["batch12"] = batch12
+        if batch128 is not None:
+            line["batch128"] = batch128
         if fp32_b12 is not None:
             line["fp32_batch12"] = fp32_b12
         if stage2 is not None:
