@@ -259,7 +259,7 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
 # Only from 32 samples per batch up: at the reference's default batch of 12 the joint pass wins (one LSTM launch over 48 items
 # instead of two over 36 and 12: 15.7 vs 16.5 ms per step).
 ASYNC_FROZEN_DECODE = os.environ.get("GA_ASYNC_FROZEN", "1") == "1"
-ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "32"))
+ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "24"))  # re-measured with the final build: B=12 15.11 vs 15.29 ms (joint wins), B=24 23.10 vs 22.97 (side stream wins)
 # High priority for the side stream: when the persistent LSTM launch and a generator conv are dispatched within ~20 us of each other,
 # the conv can be held for the LSTM's whole 2.2 ms ("dispatch-window stall"); with the LSTM's queue served first that
 # happened in 5 of 42 steps instead of 13, and four interleaved A/B pairs gave 47.07 +- 0.03 ms against 47.27 +- 0.15.
