@@ -135,6 +135,7 @@ _SIGNATURES = {
     "ga_act_bwd_bias": [_P, _P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_colsum": [_P, _I, _Z, _I, _P, _P],
     "ga_reduce": [_P, _P, _I, _Z, _I, _F, _P, _P],
+    "ga_reduce_multi": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "ga_reduce_grad": [_P, _P, _I, _Z, _I, _P, _F, _P, _I, _P],
     "ga_latent_loss_fwd": [_P, _P, _I, _I, _I, _I, _P, _P],
     "ga_latent_loss_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P],

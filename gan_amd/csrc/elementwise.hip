@@ -887,18 +887,18 @@ __device__ __forceinline__ float red_df(int op, float a, float b) {
     }
 }
 
-// 16 bytes per lane per trip when the operands are 16-byte aligned (vec != 0); scalar elements otherwise and for the tail
+// 16 bytes per lane per trip when the operands are 16-byte aligned (vec != 0); scalar elements otherwise and for the tail.
+// Block `lb` of `nb` blocks working on one (a, b, n) problem; returns the block's sum in thread 0.
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op,
-                                                      float scale, float* __restrict__ out, int vec) {
-    __shared__ float red[16];
+__device__ __forceinline__ float reduce_block(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op, int vec, int lb, int nb,
+                                              float* red) {
     constexpr int EV = 16 / sizeof(T);
     float s = 0.f;
     const size_t nv = vec ? n / EV : 0;
     // four pieces per operand and trip, all requested before the first is used (bytes in flight, not arithmetic, set the pace:
     // with one piece per trip the feature-matching sums ran at 4 TB/s)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)nb * blockDim.x;
+    size_t i = (size_t)lb * blockDim.x + threadIdx.x;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (; i + 3 * stride < nv; i += 4 * stride) {
         Pack16<T> av[4], bv[4];
@@ -922,10 +922,39 @@ __global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, co
 #pragma unroll
         for (int e = 0; e < EV; ++e) s += red_f(op, (float)av.v[e], b ? (float)bv.v[e] : 0.f);
     }
-    for (size_t k = nv * EV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+    for (size_t k = nv * EV + (size_t)lb * blockDim.x + threadIdx.x; k < n; k += stride)
         s += red_f(op, (float)a[k], b ? (float)b[k] : 0.f);
-    s = block_sum((s + s1) + (s2 + s3), red);
+    return block_sum((s + s1) + (s2 + s3), red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int op,
+                                                      float scale, float* __restrict__ out, int vec) {
+    __shared__ float red[16];
+    const float s = reduce_block<T>(a, b, n, op, vec, blockIdx.x, gridDim.x, red);
     if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+
+// several (a, b, n, scale) problems of one op summed into ONE scalar by one launch: the feature-matching term of a discriminator
+// scale is five such sums over maps of 1 GB down to 15 MB, and every launch of its own paid ~15 us of ramp and of same-address atomics
+#define GA_REDUCE_MULTI_MAX 8
+struct ReduceMultiArgs {
+    const void* a[GA_REDUCE_MULTI_MAX];
+    const void* b[GA_REDUCE_MULTI_MAX];
+    unsigned long long n[GA_REDUCE_MULTI_MAX];
+    float scale[GA_REDUCE_MULTI_MAX];
+    int start[GA_REDUCE_MULTI_MAX + 1];  // first block of each problem
+    int vec[GA_REDUCE_MULTI_MAX];
+    int cnt, op;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceMultiArgs A, float* __restrict__ out) {
+    __shared__ float red[16];
+    int i = 0;
+    while (i + 1 < A.cnt && (int)blockIdx.x >= A.start[i + 1]) ++i;
+    const float s = reduce_block<T>((const T*)A.a[i], (const T*)A.b[i], (size_t)A.n[i], A.op, A.vec[i], blockIdx.x - A.start[i],
+                                    A.start[i + 1] - A.start[i], red);
+    if (threadIdx.x == 0) atomicAdd(out, s * A.scale[i]);
 }
 
 // ga[i] (+)= coef[0] * scale * d f / d a
@@ -1405,6 +1434,42 @@ int ga_reduce(const void* a, const void* b, int dtype, size_t n, int op, float s
     const size_t work = vec ? n / (dtype == GA_DTYPE_BF16 ? 8 : 4) + 1 : n;
     DISPATCH_T(dtype, (reduce_kernel<float><<<grid_for(work, 256, 1024), 256, 0, s>>>((const float*)a, (const float*)b, n, op, scale, out, vec)),
                (reduce_kernel<bf16_t><<<grid_for(work, 256, 1024), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, n, op, scale, out, vec)));
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+int ga_reduce_multi(const void* const* a, const void* const* b, const size_t* n, const float* scale, int count, int dtype, int op, float* out,
+                    hipStream_t s) {
+    if (!a || !n || !scale || !out || count < 1 || count > GA_REDUCE_MULTI_MAX || op < 0 || op > 4) return GA_ERR_ARG;
+    if (dtype != GA_DTYPE_F32 && dtype != GA_DTYPE_BF16) return GA_ERR_ARG;
+    ReduceMultiArgs A;
+    const int ev = dtype == GA_DTYPE_BF16 ? 8 : 4;
+    double total = 0.0;
+    for (int i = 0; i < count; ++i) {
+        if (n[i] && (!a[i] || (op == GA_RED_ABSDIFF && (!b || !b[i])))) return GA_ERR_ARG;  // (an empty entry may have null pointers)
+        total += (double)n[i];
+    }
+    if (total == 0.0) return GA_OK;
+    const int cap = 1536;  // blocks in all: the large maps need ~1k blocks for bandwidth, every block costs one same-address atomic
+    int at = 0;
+    for (int i = 0; i < count; ++i) {
+        A.a[i] = a[i];
+        A.b[i] = b ? b[i] : nullptr;
+        A.n[i] = n[i];
+        A.scale[i] = scale[i];
+        A.vec[i] = (((uintptr_t)A.a[i] | (uintptr_t)A.b[i]) & 15) == 0;
+        const size_t work = A.vec[i] ? n[i] / ev + 1 : n[i];
+        long nb = (long)(cap * ((double)n[i] / total) + 0.5);
+        const long most = (long)((work + 255) / 256);
+        if (nb > most) nb = most;
+        if (nb > 1024) nb = 1024;
+        if (nb < 1) nb = 1;
+        A.start[i] = at;
+        at += (int)nb;
+    }
+    A.start[count] = at;
+    A.cnt = count;
+    A.op = op;
+    DISPATCH_T(dtype, (reduce_multi_kernel<float><<<at, 256, 0, s>>>(A, out)), (reduce_multi_kernel<bf16_t><<<at, 256, 0, s>>>(A, out)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -924,13 +924,8 @@ class DiscChainSplit(torch.autograd.Function):
         if x_fake.shape[0] != b0:
             raise ValueError("feature matching needs as many real as fake items")
         fm = zeros_f32(1, h.device)
-        ctx.fm_scales = []
-        for o in outs[:-1]:
-            half = o[b0:]
-            sc = 1.0 / (half.numel() * max(1, n - 1))
-            ctx.fm_scales.append(sc)
-            L.check(L.lib().ga_reduce(half.data_ptr(), o.data_ptr(), L.dt(o), half.numel(), L.RED_ABSDIFF, sc, fm.data_ptr(),
-                                      L.stream()), "ga_reduce")
+        ctx.fm_scales = [1.0 / (o[b0:].numel() * max(1, n - 1)) for o in outs[:-1]]
+        reduce_absdiff_multi([o[b0:] for o in outs[:-1]], [o[:b0] for o in outs[:-1]], ctx.fm_scales, fm)
         return real + tuple(o[b0:] for o in outs) + (fm.view(()),)
 
     @staticmethod
@@ -977,6 +972,28 @@ class DiscChainSplit(torch.autograd.Function):
             else:
                 ga = extra
         return tuple(grads)
+
+
+REDUCE_MULTI = os.environ.get("GA_REDUCE_MULTI", "1") == "1"
+
+
+def reduce_absdiff_multi(a_list, b_list, scales, out: Tensor) -> None:
+    """out[0] += sum_i scales[i] * sum |a_i - b_i| over contiguous tensor pairs: one launch per 8 pairs (ga_reduce_multi)."""
+    lib = L.lib()
+    if not REDUCE_MULTI:
+        for a, b, sc in zip(a_list, b_list, scales):
+            L.check(lib.ga_reduce(a.data_ptr(), b.data_ptr(), L.dt(a), a.numel(), L.RED_ABSDIFF, float(sc), out.data_ptr(), L.stream()), "ga_reduce")
+        return
+    for c0 in range(0, len(a_list), 8):
+        aa, bb, ss = a_list[c0:c0 + 8], b_list[c0:c0 + 8], scales[c0:c0 + 8]
+        k = len(aa)
+        assert all(t.is_contiguous() and t.dtype == aa[0].dtype for t in aa + bb)
+        pa = (C.c_void_p * k)(*[t.data_ptr() for t in aa])
+        pb = (C.c_void_p * k)(*[t.data_ptr() for t in bb])
+        pn = (C.c_size_t * k)(*[t.numel() for t in aa])
+        ps = (C.c_float * k)(*[float(v) for v in ss])
+        L.check(lib.ga_reduce_multi(C.cast(pa, C.c_void_p), C.cast(pb, C.c_void_p), C.cast(pn, C.c_void_p), C.cast(ps, C.c_void_p), k, L.dt(aa[0]),
+                                    L.RED_ABSDIFF, out.data_ptr(), L.stream()), "ga_reduce_multi")
 
 
 def act_fwd(x: Tensor, act: int) -> Tensor:

@@ -392,6 +392,10 @@ int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, ga_strea
 #define GA_RED_SUM 3
 #define GA_RED_SQ 4
 int ga_reduce(const void* a, const void* b, int dtype, size_t n, int op, float scale, float* out, ga_stream_t stream);
+/* `count` (<= 8) such sums, each with its own scale, added into ONE scalar by one launch: multiscale_feature_matching_loss
+ * (lab3_codec_models.py:179-186,208-215) is five l1 means per discriminator scale.  n = 0 entries are allowed. */
+int ga_reduce_multi(const void* const* a, const void* const* b, const size_t* n, const float* scale, int count, int dtype, int op,
+                    float* out, ga_stream_t stream);
 int ga_reduce_grad(const void* a, const void* b, int dtype, size_t n, int op, const float* coef, float scale, void* ga,
                    int accumulate, ga_stream_t stream);
 

@@ -1433,3 +1433,29 @@ def test_pack_cache_is_released_with_its_optimizer():
             p.mul_(0.5)
     y2 = D(torch.ones(2, 1, 2048, device=DEV))[0][0]
     assert not torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_grouped_reduction_matches_one_launch_per_pair(dtype):
+    """ga_reduce_multi (the feature-matching sums of one discriminator scale in one launch) against ga_reduce per pair and against
+    torch: sizes from 3 elements to 20 M, an odd (unaligned-tail) size, an empty entry."""
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    sizes = [20_000_003, 3_000_000, 65_536, 1001, 3, 0, 777_777]
+    aa = [torch.randn(n, device=dev).to(dtype) for n in sizes]
+    bb = [torch.randn(n, device=dev).to(dtype) for n in sizes]
+    scales = [1.0 / max(1, n) / (i + 1) for i, n in enumerate(sizes)]
+    out = torch.zeros(1, device=dev)
+    ops.reduce_absdiff_multi(aa, bb, scales, out)
+    each = torch.zeros(1, device=dev)
+    for a, b, sc in zip(aa, bb, scales):
+        if a.numel():  # (an empty tensor has no pointer to hand to the single-problem entry point)
+            L.check(L.lib().ga_reduce(a.data_ptr(), b.data_ptr(), L.dt(a), a.numel(), L.RED_ABSDIFF, float(sc), each.data_ptr(), L.stream()), "ga_reduce")
+    want = sum(sc * (a.double() - b.double()).abs().sum().item() for a, b, sc in zip(aa, bb, scales))
+    assert abs(float(out) - want) <= 2e-5 * abs(want) and abs(float(out) - float(each)) <= 2e-6 * abs(want)
+    k = 9
+    pa = (C.c_void_p * k)(*[aa[0].data_ptr()] * k)
+    pn = (C.c_size_t * k)(*[8] * k)
+    ps = (C.c_float * k)(*[1.0] * k)
+    assert L.lib().ga_reduce_multi(C.cast(pa, C.c_void_p), C.cast(pa, C.c_void_p), C.cast(pn, C.c_void_p), C.cast(ps, C.c_void_p), k, L.dt(aa[0]),
+                                   L.RED_ABSDIFF, out.data_ptr(), L.stream()) == 1  # more than 8 entries: GA_ERR_ARG
