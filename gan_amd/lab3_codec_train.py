@@ -260,11 +260,14 @@ def _backward_and_reduce(loss: torch.Tensor, opt: FusedAdamW, dp) -> None:
 # instead of two over 36 and 12: 15.7 vs 16.5 ms per step).
 ASYNC_FROZEN_DECODE = os.environ.get("GA_ASYNC_FROZEN", "1") == "1"
 ASYNC_FROZEN_MIN_BATCH = int(os.environ.get("GA_ASYNC_FROZEN_MIN_BATCH", "24"))  # re-measured with the final build: B=12 15.11 vs 15.29 ms (joint wins), B=24 23.10 vs 22.97 (side stream wins)
-# High priority for the side stream: when the persistent LSTM launch and a generator conv are dispatched within ~20 us of each other,
-# the conv can be held for the LSTM's whole 2.2 ms ("dispatch-window stall"); with the LSTM's queue served first that
-# happened in 5 of 42 steps instead of 13, and four interleaved A/B pairs gave 47.07 +- 0.03 ms against 47.27 +- 0.15.
-BUDGET_THROUGH_PRE_LSTM = os.environ.get("GA_BUDGET_PRE_LSTM", "1") == "1"
-SIDE_STREAM_PRIORITY = int(os.environ.get("GA_SIDE_PRIO", "-1"))
+# Priority of the side stream.  High priority (-1) shortens the window in which a generator conv dispatched right behind the persistent
+# LSTM launch is held for the LSTM's whole 2.2 ms ("dispatch-window stall": 5 of 42 steps instead of 13; 47.07 +- 0.03 ms
+# against 47.27 +- 0.15 in four A/B pairs) -- but with it `bench.py --force-dp --dp-overlap` DEADLOCKED, reproducibly, in the leg that
+# follows the fp32 leg (two more communication streams alive: more streams than hardware queues, one of them prioritised; the
+# main stream's barrier never completed, 70 s and counting, where every spin of our own kernels is bounded at ~4 s), and ran through
+# with priority 0.  A fifth of a millisecond is not worth a hang in the multi-GPU run: the default is 0, the knob stays for measurement.
+SIDE_STREAM_PRIORITY = int(os.environ.get("GA_SIDE_PRIO", "0"))
+BUDGET_THROUGH_PRE_LSTM = os.environ.get("GA_BUDGET_PRE_LSTM", "1") == "1"  # hold the LDS budget through the decode of q_hat's pre-LSTM convs
 ASYNC_GEMM_LDS_BUDGET = int(os.environ.get("GA_ASYNC_GEMM_LDS", str(25 * 1024)))  # 0: the generator's convs keep their usual tiles
 
 

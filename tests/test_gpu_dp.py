@@ -97,3 +97,24 @@ def test_bucket_order_follows_the_backward_pass(one_rank_group):
     first = [n for n, off in zip(names, od.offsets) if off >= sl[0][0]]
     assert first[-1].startswith("discs.2.out") and any(n.startswith("discs.2.blocks.4") for n in first)
     assert 3 <= len(sl) <= 5                                           # 85.7 MB of D gradients in 24 MiB buckets
+
+
+def test_bench_legs_run_through_under_overlapped_data_parallelism():
+    """Every leg of bench.py under a one-rank RCCL group with the all-reduce overlapped with the backward pass, in a process of its own
+    with a time limit: with a prioritised side stream this very sequence (fp32 leg, then the stage-2-like leg) deadlocked -- more streams
+    than hardware queues -- which is why gan_amd.lab3_codec_train.SIDE_STREAM_PRIORITY is 0."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GA_SIDE_PRIO="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):  # outside torchrun: bench.py opens its own one-rank group
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--force-dp", "--dp-overlap", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=str(root), env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["dp_allreduce"].startswith("overlapped")
+    for leg in ("batch12", "batch128", "stage2_like", "fp32_batch12"):
+        assert line[leg]["value"] > 0
