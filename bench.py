@@ -163,8 +163,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path (RCCL group, bucketed all-reduce) even with one rank")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape convolution timings of one step to stderr")
-    ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass (the default above one rank)")
-    ap.add_argument("--no-dp-overlap", action="store_true", help="all-reduce after the backward pass")
+    ap.add_argument("--dp-overlap", action="store_true", help="all-reduce bucket by bucket during the backward pass (opt-in: not yet run on more than one GPU)")
+    ap.add_argument("--no-dp-overlap", action="store_true", help="all-reduce after the backward pass (the default)")
     args = ap.parse_args()
     # the contract is ONE line on stdout: libraries that print banners there (RCCL prints its version at init) go to stderr
     json_fd = os.dup(1)
@@ -190,7 +190,7 @@ def main():
         if args.dp_overlap:
             dp.overlap = True
         elif args.no_dp_overlap:
-            dp.overlap = False  # (otherwise DataParallel's own default: overlapped above one rank)
+            dp.overlap = False  # (DataParallel's own default)
 
     from gan_amd import ops
     from gan_amd.lab3_codec_models import CodecTrainWeights

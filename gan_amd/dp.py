@@ -166,16 +166,16 @@ class DataParallel:
         self.world_size = dist.get_world_size(group)
         self.bucket_elems = max(1, int(bucket_bytes) // 4)
         self.exact_stft = exact_stft
-        # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward): the default as soon
-        # as there is more than one rank (north star: "all-reduce overlapped with the discriminator backward pass").  With one
-        # rank there is nothing to hide, and the side-stream collectives only cost launches.
-        # NOT YET VALIDATED ON MORE THAN ONE GPU: no multi-GPU node was available in rounds 1-3 (SCALE_r0*.json: skipped), so this
-        # default rests on the gloo world-2 CPU tests and the forced one-rank RCCL test.  What runs concurrently on hardware is
-        # RCCL's comm-stream kernels beside the persistent LSTM backward, which needs one workgroup resident on every CU; its
-        # bounded waits turn a lost residency into an error word, and check_first_overlapped_iteration() below reads it after the
-        # first overlapped iteration so a bad co-residency is reported at once instead of at the end of the epoch.
-        # `bench.py --no-dp-overlap` / DataParallel.overlap = False select the after-backward all-reduce.
-        self.overlap = self.world_size > 1
+        # True: all-reduce each bucket while the backward pass is still running (begin/finish_backward; north star: "all-reduce
+        # overlapped with the discriminator backward pass").  OPT-IN (`DataParallel.overlap = True`, `bench.py --dp-overlap`): the path
+        # has never run on more than one GPU (no multi-GPU node in rounds 1-3: SCALE_r0*.json skipped) -- it rests on the gloo
+        # world-2 CPU tests and the forced one-rank RCCL tests -- and its extra streams have already produced one deadlock on a
+        # single GPU (a prioritised side stream beside the communication streams, lab3_codec_train.SIDE_STREAM_PRIORITY).  What runs
+        # concurrently on hardware is RCCL's kernels beside the persistent LSTM backward, which needs one workgroup resident on
+        # every CU; its bounded waits turn a lost residency into an error word, and check_first_overlapped_iteration() below reads it
+        # after the first overlapped iteration.  The default, all-reduce after the backward pass, costs the un-hidden collective:
+        # 135 MB of gradients per step, ~2-3 ms over xGMI at 8 GPUs against a 47 ms step.
+        self.overlap = False
         self._overlap_checked = False
 
     def check_first_overlapped_iteration(self, device) -> None:
