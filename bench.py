@@ -387,6 +387,8 @@ def main():
                                  for k, v in sorted(kernels.items())},
             "loss_g_last": round(loss_g, 5),
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+            "reserved_hbm_gb": round(torch.cuda.max_memory_reserved(device) / 1e9, 2),
+            "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),
         }
         if batch12 is not None:
             line["batch12"] = batch12

@@ -132,6 +132,12 @@ _SIGNATURES = {
     "ga_act_fwd": [_P, _P, _I, _Z, _I, _P],
     "ga_rowgather_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ga_rowgather_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ga_cnorm_supported": [_I, _I, C.c_long, _I, _I],
+    "ga_cnorm_stats": [_P, _I, _I, C.c_long, _I, _I, _P, _P],
+    "ga_cnorm_finalize": [_P, _I, _I, C.c_long, _I, _I, _P, _F, _P, _P, _P, _P, _F, _P],
+    "ga_cnorm_apply": [_P, _P, _I, _I, C.c_long, _I, _I, _P, _P, _P, _P, _I, _P],
+    "ga_cnorm_bwd_stats": [_P, _P, _P, _I, _I, C.c_long, _I, _I, _P, _P, _I, _P, _P],
+    "ga_cnorm_bwd_apply": [_P, _P, _P, _P, _I, _I, C.c_long, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "ga_act_bwd_bias": [_P, _P, _P, _I, _Z, _I, _I, _P, _P],
     "ga_colsum": [_P, _I, _Z, _I, _P, _P],
     "ga_reduce": [_P, _P, _I, _Z, _I, _F, _P, _P],

@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libgan_amd.so"
-SOURCES = ["capi.hip", "conv_direct.hip", "conv_mfma.hip", "conv_gemm.hip", "conv_pp.hip", "conv_win.hip", "conv_stream.hip", "conv_swin.hip", "resunit.hip", "conv_coop.hip", "wgrad_mfma.hip", "wgrad_gemm.hip", "wgrad_cin1_mfma.hip", "thin.hip", "lstm.hip", "lstm_persist.hip", "elementwise.hip", "stft.hip"]
+SOURCES = ["capi.hip", "conv_direct.hip", "conv_mfma.hip", "conv_gemm.hip", "conv_pp.hip", "conv_win.hip", "conv_stream.hip", "conv_swin.hip", "resunit.hip", "conv_coop.hip", "wgrad_mfma.hip", "wgrad_gemm.hip", "wgrad_cin1_mfma.hip", "thin.hip", "lstm.hip", "lstm_persist.hip", "elementwise.hip", "cnorm.hip", "stft.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

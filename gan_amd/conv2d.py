@@ -12,6 +12,8 @@ Reference layers this serves: nn.Conv2d / nn.ConvTranspose2d in /root/reference/
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -110,6 +112,91 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 # ConvTranspose2d(kernel 4, stride 2, padding 1): y[2t + phi] = sum over the two kernel taps of phase phi.  Along one axis
 #   phi = 0: x[t-1] * w[3] + x[t] * w[1]        phi = 1: x[t] * w[2] + x[t+1] * w[0]
 # i.e. a 3-tap convolution (offsets -1, 0, +1) whose taps are a subset of the 4-tap kernel: {tap: kernel index} per phase.
+FUSED_NORM = os.environ.get("GA_MEL_FUSED_NORM", "1") != "0"  # 0: the norm layers run as the torch modules (A/B and bisecting)
+
+
+class ChannelNorm(torch.autograd.Function):
+    """InstanceNorm2d (groups = B) / BatchNorm2d (groups = 1) on a contiguous channels-last [B, H, W, C] tensor with an optional
+    LeakyReLU(0.2) behind it: ga_cnorm_stats -> ga_cnorm_finalize -> ga_cnorm_apply forward, ga_cnorm_bwd_stats -> ga_cnorm_bwd_apply
+    backward.  `running` = (running_mean, running_var, momentum) updates BatchNorm's buffers in training; `frozen` = (mean, rstd) uses
+    given statistics (BatchNorm in eval mode).  First-order only: gradient penalties keep the torch modules (`twice_differentiable`)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups: int, eps: float, act: int, running, frozen):
+        B, H, W, C = x.shape
+        HW = H * W
+        lib, st = L.lib(), L.stream()
+        if frozen is None:
+            sums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)
+            mean = torch.empty((groups, C), device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            L.check(lib.ga_cnorm_stats(x.data_ptr(), L.dt(x), B, HW, C, groups, sums.data_ptr(), st), "ga_cnorm_stats")
+            rm, rv, mom = running if running is not None else (None, None, 0.0)
+            L.check(lib.ga_cnorm_finalize(x.data_ptr(), L.dt(x), B, HW, C, groups, sums.data_ptr(), float(eps), mean.data_ptr(), rstd.data_ptr(),
+                                          L.ptr(rm), L.ptr(rv), float(mom), st), "ga_cnorm_finalize")
+        else:
+            mean, rstd = frozen
+        y = torch.empty_like(x)
+        L.check(lib.ga_cnorm_apply(x.data_ptr(), y.data_ptr(), L.dt(x), B, HW, C, groups, mean.data_ptr(), rstd.data_ptr(), L.ptr(gamma),
+                                   L.ptr(beta), act, st), "ga_cnorm_apply")
+        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, mean, rstd, gamma)
+        ctx.cfg = (groups, act, frozen is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        groups, act, frozen, has_beta = ctx.cfg
+        B, H, W, C = x.shape
+        HW = H * W
+        gy = gy.contiguous()
+        lib, st = L.lib(), L.stream()
+        gsums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)  # per item: few atomics per address
+        L.check(lib.ga_cnorm_bwd_stats(gy.data_ptr(), x.data_ptr(), L.ptr(y), L.dt(x), B, HW, C, groups, mean.data_ptr(), rstd.data_ptr(), act,
+                                       gsums.data_ptr(), st), "ga_cnorm_bwd_stats")
+        gsum = gsums.sum(0)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.check(lib.ga_cnorm_bwd_apply(gy.data_ptr(), x.data_ptr(), L.ptr(y), gx.data_ptr(), L.dt(x), B, HW, C, groups, mean.data_ptr(),
+                                           rstd.data_ptr(), L.ptr(gamma), (gsum if groups == 1 else gsums).data_ptr(), act, int(frozen), st),
+                    "ga_cnorm_bwd_apply")
+        ggamma = gsum[:, 1].to(gamma.dtype) if gamma is not None and ctx.needs_input_grad[1] else None
+        gbeta = gsum[:, 0].to(gamma.dtype) if has_beta and ctx.needs_input_grad[2] else None
+        return gx, ggamma, gbeta, None, None, None, None, None
+
+
+def norm2d_supported(m: torch.nn.Module, h_nchw: torch.Tensor) -> bool:
+    """Whether `norm2d_nhwc` takes this layer on this input (otherwise the torch module runs)."""
+    if not FUSED_NORM or TWICE_DIFFERENTIABLE or h_nchw.dim() != 4 or h_nchw.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    B, C, H, W = h_nchw.shape
+    if isinstance(m, torch.nn.InstanceNorm2d):
+        if m.track_running_stats or (m.affine and m.weight.dtype != torch.float32):
+            return False
+        groups = B
+    elif isinstance(m, torch.nn.BatchNorm2d):
+        if not m.track_running_stats or m.momentum is None or (m.affine and m.weight.dtype != torch.float32):
+            return False
+        groups = 1
+    else:
+        return False
+    return bool(L.lib().ga_cnorm_supported(L.DT_BF16 if h_nchw.dtype == torch.bfloat16 else L.DT_F32, B, H * W, C, groups))
+
+
+def norm2d_nhwc(m: torch.nn.Module, x: torch.Tensor, post_act: int = L.ACT_NONE) -> torch.Tensor:
+    """nn.InstanceNorm2d / nn.BatchNorm2d `m` (its parameters, buffers, eps, momentum and training flag) on a contiguous channels-last
+    [B, H, W, C] tensor, with LeakyReLU(0.2) behind it when post_act = ACT_LRELU."""
+    gamma, beta = (m.weight, m.bias) if m.affine else (None, None)
+    if isinstance(m, torch.nn.InstanceNorm2d):
+        return ChannelNorm.apply(x, gamma, beta, x.shape[0], m.eps, post_act, None, None)
+    if m.training:
+        m.num_batches_tracked += 1
+        return ChannelNorm.apply(x, gamma, beta, 1, m.eps, post_act, (m.running_mean, m.running_var, float(m.momentum)), None)
+    frozen = (m.running_mean.float().view(1, -1).contiguous(), torch.rsqrt(m.running_var.float() + m.eps).view(1, -1).contiguous())
+    return ChannelNorm.apply(x, gamma, beta, 1, m.eps, post_act, None, frozen)
+
+
 _TAPS = ({0: 3, 1: 1}, {1: 2, 2: 0})
 _TAP_INDEX = {}
 

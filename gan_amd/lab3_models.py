@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch.nn.utils.spectral_norm import SpectralNorm
 
 from . import _lib as L
-from .conv2d import conv2d_nhwc, conv_transpose2d_k4s2p1_nhwc, to_nchw_view, to_nhwc
+from .conv2d import conv2d_nhwc, conv_transpose2d_k4s2p1_nhwc, norm2d_nhwc, norm2d_supported, to_nchw_view, to_nhwc
 
 
 def _maybe_sn(layer: nn.Module, flag: bool) -> nn.Module:
@@ -67,6 +67,11 @@ def _run(layers: Sequence[nn.Module], h: torch.Tensor) -> torch.Tensor:
                     raise NotImplementedError("square stride / padding, no dilation, no groups")
                 y = conv2d_nhwc(x, _weight_of(m), m.bias, int(m.stride[0]), int(m.padding[0]), act)
             h = to_nchw_view(y)
+            i += 2 if fuse else 1
+            continue
+        if isinstance(m, (nn.InstanceNorm2d, nn.BatchNorm2d)) and norm2d_supported(m, h):
+            fuse = i + 1 < n and isinstance(layers[i + 1], nn.LeakyReLU) and abs(layers[i + 1].negative_slope - 0.2) < 1e-12
+            h = to_nchw_view(norm2d_nhwc(m, to_nhwc(h), L.ACT_LRELU if fuse else L.ACT_NONE))
             i += 2 if fuse else 1
             continue
         if isinstance(m, nn.PixelShuffle):
