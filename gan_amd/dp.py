@@ -20,6 +20,46 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo takes CUDA tensors for broadcast and all_reduce, but moves them on HIGH-PRIORITY pool streams of its own; on this stack a
+    prioritised stream beside more streams than hardware queues has deadlocked twice (lab3_codec_train.SIDE_STREAM_PRIORITY; two gloo
+    ranks sharing one GPU, tests/test_gpu_dp_two_ranks.py), so under gloo a device tensor goes through the host explicitly: a blocking
+    copy out, the collective on the CPU tensor, a copy back.  Slow and never overlapped -- gloo is the test / fallback backend, RCCL
+    ("nccl") is the product's."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _StagedWork:
+    """all_reduce of a device tensor through the host (see _host_staged); wait() finishes it."""
+
+    def __init__(self, t: torch.Tensor, group):
+        self.t, self.host = t, t.detach().cpu()  # synchronises the current stream with the host
+        self.work = dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def wait(self) -> None:
+        self.work.wait()
+        self.t.copy_(self.host)
+
+
+def all_reduce_sum(t: torch.Tensor, group, async_op: bool = False):
+    if _host_staged(t, group):
+        w = _StagedWork(t, group)
+        if async_op:
+            return w
+        w.wait()
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast(t: torch.Tensor, src: int, group) -> None:
+    if _host_staged(t, group):
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
 class _AllReduceSums(torch.autograd.Function):
     """forward: SUM over ranks.  backward: gradient times world_size - every rank then holds d(GLOBAL loss)/d(its own
     shard) * W, and the optimizer's mean over ranks (grad_scale = 1/W) turns the sum of those partial gradients into the
@@ -28,7 +68,7 @@ class _AllReduceSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, group):
         out = t.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(out, group)
         ctx.world = dist.get_world_size(group)
         return out
 
@@ -136,14 +176,14 @@ class _OverlapState:
             self.sink.flush(only=deferred)
         a, e = self.slices[b]
         chunk = self.opt.flat_g[a:e]
-        if self.cuda:
+        if self.cuda and not _host_staged(chunk, self.dp.group):
             ev = torch.cuda.Event()
             ev.record()  # the copies into this bucket are on the current (main) stream
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
                 self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True))
         else:
-            self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True))
+            self.works.append(all_reduce_sum(chunk, self.dp.group, async_op=True))
 
     def finish(self) -> None:
         self.active = False
@@ -231,11 +271,27 @@ class DataParallel:
                 end = offsets[i]
         return out
 
+    def sync_sqnorm(self, sq: torch.Tensor) -> None:
+        """The clip coefficient has to be the SAME NUMBER on every rank.  After the all-reduce the ranks hold bit-identical gradients,
+        but sum(g^2) is taken with floating-point atomics whose order differs from launch to launch, so each rank would clip by its
+        own last bits and the replicas would drift apart (found by tests/test_gpu_dp_two_ranks.py: parameters equal across ranks in
+        one run, unequal in the next).  MAX over ranks of the one-float device scalar, on the stream, between the norm kernel and
+        the AdamW kernel (installed as opt.sqnorm_hook)."""
+        if self.world_size == 1:
+            return
+        if _host_staged(sq, self.group):
+            host = sq.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            sq.copy_(host)
+        else:
+            dist.all_reduce(sq, op=dist.ReduceOp.MAX, group=self.group)
+
     def allreduce_flat(self, opt) -> None:
         """SUM-all-reduce opt.flat_g bucket by bucket; the mean is applied inside the AdamW kernel."""
+        opt.sqnorm_hook = self.sync_sqnorm
         works = []
         for a, b in self.bucket_slices_for(opt):
-            works.append(dist.all_reduce(opt.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            works.append(all_reduce_sum(opt.flat_g[a:b], self.group, async_op=True))
         for w in works:
             w.wait()
         opt.grad_scale = 1.0 / float(self.world_size)
@@ -260,6 +316,7 @@ class DataParallel:
 
     def finish_backward(self, opt) -> None:
         opt._dp_overlap.finish()
+        opt.sqnorm_hook = self.sync_sqnorm
         opt.grad_scale = 1.0 / float(self.world_size)
 
     def stft_sum_hook(self, sums: torch.Tensor, count: float):
@@ -274,10 +331,10 @@ class DataParallel:
         self.broadcast_params(*opts)
         meta = torch.tensor([float(start_epoch)] + [float(o.step_count) for o in opts], dtype=torch.float64,
                             device=opts[0].flat_p.device)
-        dist.broadcast(meta, src=0, group=self.group)
+        broadcast(meta, 0, self.group)
         for opt in opts:
-            dist.broadcast(opt.exp_avg, src=0, group=self.group)
-            dist.broadcast(opt.exp_avg_sq, src=0, group=self.group)
+            broadcast(opt.exp_avg, 0, self.group)
+            broadcast(opt.exp_avg_sq, 0, self.group)
         vals = meta.tolist()
         for o, v in zip(opts, vals[1:]):
             o.step_count = int(v)
@@ -285,7 +342,7 @@ class DataParallel:
 
     def broadcast_params(self, *opts) -> None:
         for opt in opts:
-            dist.broadcast(opt.flat_p, src=0, group=self.group)
+            broadcast(opt.flat_p, 0, self.group)
             epoch = getattr(opt, "_epoch", None)
             if epoch is not None:
                 epoch[0] += 1  # parameters rewritten in place: cached weight packs are stale

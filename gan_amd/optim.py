@@ -52,6 +52,7 @@ class FusedAdamW:
         weakref.finalize(self, ops.unregister_param_range, lo, hi)  # packs and epoch go when this optimizer does
         self.last_grad_norm: Optional[torch.Tensor] = None
         self.grad_scale = 1.0  # 1/world_size when flat_g holds a SUM over ranks
+        self.sqnorm_hook = None  # called with the device scalar sum(g^2) between the norm kernel and the AdamW kernel
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
@@ -79,6 +80,8 @@ class FusedAdamW:
         lib = L.lib()
         self._sq.zero_()
         L.check(lib.ga_grad_sqnorm(self.flat_g.data_ptr(), self.numel, self._sq.data_ptr(), L.stream()), "ga_grad_sqnorm")
+        if self.sqnorm_hook is not None:
+            self.sqnorm_hook(self._sq)  # data parallel: every rank clips by the same number (gan_amd/dp.py::DataParallel.sync_sqnorm)
         L.check(lib.ga_adamw_fused(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                    self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
                                    self.weight_decay, self.step_count, self.max_grad_norm, float(self.grad_scale),
