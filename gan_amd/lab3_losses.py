@@ -23,9 +23,10 @@ from . import ops
 
 def multi_resolution_stft_loss(mel_pred: torch.Tensor, mel_true: torch.Tensor,
                                resolutions: Iterable[Tuple[int, int, int]] = ((64, 16, 64), (128, 32, 128), (256, 64, 256)),
-                               precision: str = "fp32") -> torch.Tensor:
+                               precision: str = "fp32", sum_hook=None) -> torch.Tensor:
     """reference lab3_losses.py:16-71 (same name, arguments and ValueError).  The gradient flows to `mel_pred`; `mel_true` is
-    treated as data (detached), which is how the mel track uses it."""
+    treated as data (detached), which is how the mel track uses it.  `sum_hook` (data parallel, gan_amd.dp.DataParallel.stft_sum_hook)
+    may all-reduce a resolution's three sums so that the spectral-convergence ratio is the global batch's."""
     if mel_pred.shape != mel_true.shape:
         raise ValueError(f"Shape mismatch: {mel_pred.shape} vs {mel_true.shape}")
     L.require_cuda(mel_pred, mel_true)
@@ -40,8 +41,11 @@ def multi_resolution_stft_loss(mel_pred: torch.Tensor, mel_true: torch.Tensor,
         # (the split-bf16 GEMM stages 16-byte pieces of the 3 x hop framed channels and its data gradient has hop output channels:
         # hops below 16 or not a multiple of 8 -- toy sizes -- take the exact fp32 kernel)
         sums = ops.StftSums.apply(x, y, n_fft, hop, win, precision == "bf16" and hop >= 16 and hop % 8 == 0, True)
+        count = float(b * n_mels * (n_fft // 2 + 1) * (1 + t // hop))
+        if sum_hook is not None:
+            sums, count = sum_hook(sums, count)
         per_res.append(sums)
-        inv_counts.append(1.0 / float(b * n_mels * (n_fft // 2 + 1) * (1 + t // hop)))
+        inv_counts.append(1.0 / count)
     if not per_res:
         return ops.reduce_sum(mel_pred, mel_true.detach(), L.RED_ABSDIFF, 1.0 / mel_pred.numel())
     return ops.StftCombine.apply(torch.stack(per_res), ops.const_vec(inv_counts, x.device))

@@ -236,19 +236,26 @@ def _cosine_distance(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return 1.0 - F.cosine_similarity(a, b, dim=-1)
 
 
-def _backward_step(loss: torch.Tensor, opt: FusedAdamW, clip: float) -> None:
+def _backward_step(loss: torch.Tensor, opt: FusedAdamW, clip: float, dp=None) -> None:
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.max_grad_norm = float(clip) if float(clip) > 0.0 else 0.0
-    opt.step()
+    if dp is None:
+        opt.step()
+        return
+    opt.gather_grads()
+    dp.allreduce_flat(opt)  # SUM over ranks in buckets; the mean and the common clip coefficient are applied by the AdamW launch
+    opt.step(grads_gathered=True)
 
 
 def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, opt_g: FusedAdamW, opt_d: FusedAdamW,
                          real: torch.Tensor, zc: torch.Tensor, cond: torch.Tensor, step_idx: int, zs: Optional[torch.Tensor] = None,
-                         frozen_encoder=None) -> Dict[str, torch.Tensor]:
+                         frozen_encoder=None, dp=None) -> Dict[str, torch.Tensor]:
     """One pass of train_stage1's loop body (reference lab3_train.py:380-456).  Returns device scalars (no host sync).
     frozen_encoder (+ zs): the caller's frozen Lab1 encoder for the content / style terms (:432-435); without it they stay at
-    zero and nonzero weights for them are an error, not a silent drop."""
+    zero and nonzero weights for them are an error, not a silent drop.  dp (gan_amd.dp.DataParallel, not in the reference): this
+    rank's shard of the batch; gradients are all-reduced before each optimizer step, the MR-STFT ratio is the global batch's, and the
+    discriminator's BatchNorm statistics are this rank's own (what DistributedDataParallel without SyncBN conversion does)."""
     w = stage_cfg.weights
     if frozen_encoder is None and (float(w.content) != 0.0 or float(w.style) != 0.0) and not stage_cfg.extra.get("allow_missing_encoder", False):
         raise ValueError("weights.content / weights.style need the frozen Lab1 encoder (pass frozen_encoder, or set them to 0)")
@@ -266,7 +273,7 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
         if float(stage_cfg.r1_gamma) > 0.0 and (int(step_idx) % int(max(1, stage_cfg.r1_interval)) == 0):
             r1 = 0.5 * float(stage_cfg.r1_gamma) * _r1_penalty(discriminator, real, cond_d)
             loss_d = loss_d + r1
-        _backward_step(loss_d, opt_d, stage_cfg.d_grad_clip_norm)
+        _backward_step(loss_d, opt_d, stage_cfg.d_grad_clip_norm, dp)
     # G step (:418-451)
     fake = generator(zc, cond)
     d_params = list(discriminator.parameters())
@@ -280,7 +287,8 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
             p.requires_grad_(r)
     loss_adv = _gan_g_loss(stage_cfg.gan_loss, logit_fake_g, float(stage_cfg.g_real_label), float(stage_cfg.d_fake_label))
     loss_l1 = F.l1_loss(fake, real)
-    loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions, precision=getattr(generator, "precision", "fp32"))
+    loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions, precision=getattr(generator, "precision", "fp32"),
+                                                 sum_hook=None if dp is None else dp.stft_sum_hook)
     loss_mrstft = loss_continuity
     loss_content = loss_style = zero
     if frozen_encoder is not None:
@@ -290,7 +298,7 @@ def mel_stage1_iteration(stage_cfg: StageTrainConfig, generator, discriminator, 
             loss_style = _cosine_distance(enc["z_style"], zs).mean()
     loss_g = (w.adv * loss_adv + w.recon_l1 * loss_l1 + w.content * loss_content + w.style * loss_style
               + w.continuity * loss_continuity + w.mrstft * loss_mrstft)
-    _backward_step(loss_g, opt_g, stage_cfg.g_grad_clip_norm)
+    _backward_step(loss_g, opt_g, stage_cfg.g_grad_clip_norm, dp)
     out.update(loss_g=loss_g.detach(), loss_d=loss_d.detach(), loss_r1=r1.detach(), loss_adv=loss_adv.detach(), loss_l1=loss_l1.detach(),
                loss_content=loss_content.detach(), loss_style=loss_style.detach(), loss_continuity=loss_continuity.detach(),
                loss_mrstft=loss_mrstft.detach(), d_step=torch.tensor(1.0 if do_d_step else 0.0))
@@ -328,14 +336,19 @@ def _load_stage_checkpoint(path: Path, generator, discriminator, opt_g, opt_d, s
 
 
 def train_stage1(generator, discriminator, frozen_encoder, train_loader, cond_bank: torch.Tensor, device, stage_cfg: StageTrainConfig,
-                 checkpoint_path: Path, resume: bool = False) -> List[Dict]:
-    """reference lab3_train.py:342-483: same arguments, same per-epoch history rows (nine loss means, stage, epoch, d-step counts)."""
+                 checkpoint_path: Path, resume: bool = False, dp=None) -> List[Dict]:
+    """reference lab3_train.py:342-483: same arguments, same per-epoch history rows (nine loss means, stage, epoch, d-step counts).
+    dp (gan_amd.dp.DataParallel, one process per GPU, `train_loader` yielding this rank's shard): rank 0's parameters, moments and resume
+    epoch go to every rank, gradients are all-reduced per optimizer step, the history rows are means over the global batch on every rank,
+    and rank 0 alone writes the checkpoint.  BatchNorm buffers stay per rank (rank 0's are the ones saved)."""
     generator.train()
     discriminator.train()
     cond_bank = cond_bank.to(device)
     opt_g = FusedAdamW(generator.parameters(), lr=stage_cfg.lr_g, betas=stage_cfg.betas, weight_decay=0.0)
     opt_d = FusedAdamW(discriminator.parameters(), lr=stage_cfg.lr_d, betas=stage_cfg.betas, weight_decay=0.0)
     start_epoch = _load_stage_checkpoint(checkpoint_path, generator, discriminator, opt_g, opt_d) if resume else 0
+    if dp is not None:
+        start_epoch = dp.broadcast_state(start_epoch, opt_g, opt_d)
     keys = ("loss_g", "loss_d", "loss_r1", "loss_adv", "loss_l1", "loss_content", "loss_style", "loss_continuity", "loss_mrstft")
     history: List[Dict] = []
     step_idx = 0
@@ -350,18 +363,26 @@ def train_stage1(generator, discriminator, frozen_encoder, train_loader, cond_ba
             zs = batch["z_style"].to(device).float()
             cond = cond_bank[batch["genre_idx"].to(device).long()]
             out = mel_stage1_iteration(stage_cfg, generator, discriminator, opt_g, opt_d, real, zc, cond, step_idx, zs=zs,
-                                       frozen_encoder=frozen_encoder)
+                                       frozen_encoder=frozen_encoder, dp=dp)
             sums += torch.stack([out[k].float().reshape(()) for k in keys])  # one host read per epoch, not nine per iteration
             taken += int((step_idx % int(max(1, stage_cfg.d_step_period))) == 0)
             nb += 1
             step_idx += 1
-        means = (sums / max(1, nb)).tolist()
+        n_terms = float(max(1, nb))
+        if dp is not None and dp.world_size > 1:  # loss sums and iteration counts over all ranks: the row is the global batch's mean
+            host = {k: float(v) for k, v in zip(keys, sums.tolist())}
+            counts = {"nb": float(nb)}
+            dp.reduce_history_means(host, counts)
+            sums = torch.tensor([host[k] for k in keys])
+            n_terms = max(1.0, counts["nb"])
+        means = (sums / n_terms).tolist()
         ep: Dict = {k: float(v) for k, v in zip(keys, means)}
         ep.update(stage="stage1", epoch=int(epoch + 1), d_steps_taken=float(taken), d_steps_skipped=float(nb - taken),
                   d_step_rate=float(taken / max(1, nb)))
         history.append(ep)
-        _save_stage_checkpoint(checkpoint_path, int(epoch + 1), generator, discriminator, opt_g, opt_d, meta={"stage": "stage1"})
-        print(f"[stage1] epoch={epoch + 1} loss_g={ep['loss_g']:.4f} loss_d={ep['loss_d']:.4f}")
+        if dp is None or dp.rank == 0:
+            _save_stage_checkpoint(checkpoint_path, int(epoch + 1), generator, discriminator, opt_g, opt_d, meta={"stage": "stage1"})
+            print(f"[stage1] epoch={epoch + 1} loss_g={ep['loss_g']:.4f} loss_d={ep['loss_d']:.4f}")
     return history
 
 
