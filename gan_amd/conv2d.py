@@ -127,7 +127,7 @@ class ChannelNorm(torch.autograd.Function):
         HW = H * W
         lib, st = L.lib(), L.stream()
         if frozen is None:
-            sums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)
+            sums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float64)
             mean = torch.empty((groups, C), device=x.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
             L.check(lib.ga_cnorm_stats(x.data_ptr(), L.dt(x), B, HW, C, groups, sums.data_ptr(), st), "ga_cnorm_stats")
@@ -151,7 +151,7 @@ class ChannelNorm(torch.autograd.Function):
         HW = H * W
         gy = gy.contiguous()
         lib, st = L.lib(), L.stream()
-        gsums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float32)  # per item: few atomics per address
+        gsums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float64)  # per item: few atomics per address; double: their order does not show
         L.check(lib.ga_cnorm_bwd_stats(gy.data_ptr(), x.data_ptr(), L.ptr(y), L.dt(x), B, HW, C, groups, mean.data_ptr(), rstd.data_ptr(), act,
                                        gsums.data_ptr(), st), "ga_cnorm_bwd_stats")
         gsum = gsums.sum(0)

@@ -9,7 +9,9 @@
 // channels -- and with them gamma, beta, mean, rstd -- are fixed for the whole launch and live in registers.
 //
 // Sums are taken about a PIVOT (the group's first row), sum(x - p) and sum((x - p)^2), so that var = E[(x-p)^2] - E[x-p]^2 does not
-// cancel when |mean| >> std; partial sums meet in LDS (ds_add_f32) and leave as one global atomicAdd per channel and block into PER-ITEM
+// cancel when |mean| >> std; a thread's fp32 partial sums (a fixed set of rows: deterministic) meet in LDS and leave as one global atomicAdd
+// per channel and block, both in DOUBLE, so that the order of the atomics shows at 1e-16 and not at 1e-7 (with float atomics a three-layer
+// decoder's output moved by up to 1e-6 from run to run, enough to cross a 2e-6 parity bound now and then); they go into PER-ITEM
 // sums [B][C][2] (a batch norm's 2048 blocks on one address per channel cost 15-20 us of serialised atomics); the finalize kernel / the
 // caller adds the items of a group.
 #include "common.h"
@@ -26,10 +28,10 @@ template <typename T> struct alignas(16) CnPack { T v[16 / sizeof(T)]; };
     (void)g; (void)item; (void)c0; (void)active
 
 template <typename T>
-__global__ __launch_bounds__(256) void cnorm_stats_kernel(const T* __restrict__ x, int HW, int C, int groups, float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void cnorm_stats_kernel(const T* __restrict__ x, int HW, int C, int groups, double* __restrict__ sums) {
     CN_MAP();
-    extern __shared__ float acc[];  // [C][2]
-    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.f;
+    extern __shared__ double acc[];  // [C][2]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.0;
     __syncthreads();
     if (active) {
         const CnPack<T> pv = *(const CnPack<T>*)(x + (groups == 1 ? (size_t)0 : item) + c0);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void cnorm_stats_kernel(const T* __restrict__ 
         }
         for (; r < HW; r += step) add(*(const CnPack<T>*)(x + item + (size_t)r * C + c0));
 #pragma unroll
-        for (int e = 0; e < EV; ++e) { atomicAdd(&acc[2 * (c0 + e)], s1[e]); atomicAdd(&acc[2 * (c0 + e) + 1], s2[e]); }
+        for (int e = 0; e < EV; ++e) { atomicAdd(&acc[2 * (c0 + e)], (double)s1[e]); atomicAdd(&acc[2 * (c0 + e) + 1], (double)s2[e]); }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[(size_t)b * 2 * C + i], acc[i]);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void cnorm_stats_kernel(const T* __restrict__ 
 
 // mean / rstd per (group, channel); BatchNorm's running statistics (momentum update, unbiased variance) when given
 template <typename T>
-__global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, int C, int groups, const float* __restrict__ sums, float eps,
+__global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, int C, int groups, const double* __restrict__ sums, float eps,
                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                       float* __restrict__ run_var, float momentum) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,12 +73,12 @@ __global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, in
         t1 += sums[2 * ((size_t)bb * C + c)];
         t2 += sums[2 * ((size_t)bb * C + c) + 1];
     }
-    const float m1 = (float)(t1 / n);
-    float var = (float)(t2 / n) - m1 * m1;
-    var = var > 0.f ? var : 0.f;
-    const float mu = p + m1;
+    const double m1 = t1 / n;  // (double from here on: a handful of operations per channel)
+    double var = t2 / n - m1 * m1;
+    var = var > 0.0 ? var : 0.0;
+    const float mu = (float)((double)p + m1);
     mean[i] = mu;
-    rstd[i] = 1.f / sqrtf(var + eps);
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean && groups == 1) {
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
@@ -115,10 +117,10 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void cnorm_bwd_stats_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y, int HW,
                                                               int C, int groups, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, int act, float* __restrict__ gsums) {
+                                                              const float* __restrict__ rstd, int act, double* __restrict__ gsums) {
     CN_MAP();
-    extern __shared__ float acc[];
-    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.f;
+    extern __shared__ double acc[];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.0;
     __syncthreads();
     if (active) {
         float mu[EV], rs[EV], s1[EV], s2[EV];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void cnorm_bwd_stats_kernel(const T* __restric
             add(*(const CnPack<T>*)(gy + o), *(const CnPack<T>*)(x + o), *(const CnPack<T>*)(yy + o));
         }
 #pragma unroll
-        for (int e = 0; e < EV; ++e) { atomicAdd(&acc[2 * (c0 + e)], s1[e]); atomicAdd(&acc[2 * (c0 + e) + 1], s2[e]); }
+        for (int e = 0; e < EV; ++e) { atomicAdd(&acc[2 * (c0 + e)], (double)s1[e]); atomicAdd(&acc[2 * (c0 + e) + 1], (double)s2[e]); }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsums[(size_t)b * 2 * C + i], acc[i]);
@@ -158,19 +160,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void cnorm_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y,
                                                               T* __restrict__ gx, int B, int HW, int C, int groups,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ gamma, const float* __restrict__ gsums, int act,
+                                                              const float* __restrict__ gamma, const double* __restrict__ gsums, int act,
                                                               int frozen) {
     CN_MAP();
     if (!active) return;
-    const float inv_n = frozen ? 0.f : 1.f / (groups == 1 ? (float)B * (float)HW : (float)HW);
+    const double inv_n = frozen ? 0.0 : 1.0 / (groups == 1 ? (double)B * (double)HW : (double)HW);
     float mu[EV], rs[EV], k[EV], a1[EV], a2[EV];
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
         mu[e] = mean[(size_t)g * C + c0 + e];
         rs[e] = rstd[(size_t)g * C + c0 + e];
         k[e] = rs[e] * (gamma ? gamma[c0 + e] : 1.f);
-        a1[e] = gsums[2 * ((size_t)g * C + c0 + e)] * inv_n;
-        a2[e] = gsums[2 * ((size_t)g * C + c0 + e) + 1] * inv_n;
+        a1[e] = (float)(gsums[2 * ((size_t)g * C + c0 + e)] * inv_n);
+        a2[e] = (float)(gsums[2 * ((size_t)g * C + c0 + e) + 1] * inv_n);
     }
     for (int r = blockIdx.x * rpp + rl; r < HW; r += gridDim.x * rpp) {
         const size_t o = item + (size_t)r * C + c0;
@@ -219,20 +221,20 @@ extern "C" {
 
 int ga_cnorm_supported(int dtype, int B, long HW, int C, int groups) { return cn_check(dtype, B, HW, C, groups) == GA_OK; }
 
-int ga_cnorm_stats(const void* x, int dtype, int B, long HW, int C, int groups, float* sums, hipStream_t s) {
+int ga_cnorm_stats(const void* x, int dtype, int B, long HW, int C, int groups, double* sums, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
     if (!x || !sums) return GA_ERR_ARG;
     if (((uintptr_t)x) & 15) return GA_ERR_ALIGN;
     const dim3 grid = cn_grid(dtype, B, HW, C, true);
-    const size_t lds = (size_t)2 * C * sizeof(float);
+    const size_t lds = (size_t)2 * C * sizeof(double);
     CN_DISPATCH(dtype, (cnorm_stats_kernel<float><<<grid, 256, lds, s>>>((const float*)x, (int)HW, C, groups, sums)),
                 (cnorm_stats_kernel<bf16_t><<<grid, 256, lds, s>>>((const bf16_t*)x, (int)HW, C, groups, sums)));
     GA_CHECK_LAUNCH();
     return GA_OK;
 }
 
-int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const float* sums, float eps, float* mean, float* rstd,
+int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const double* sums, float eps, float* mean, float* rstd,
                       float* running_mean, float* running_var, float momentum, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
@@ -260,13 +262,13 @@ int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int
 }
 
 int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, int act, float* gsums, hipStream_t s) {
+                       const float* rstd, int act, double* gsums, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
     if (!gy || !x || !mean || !rstd || !gsums || (act != GA_ACT_NONE && act != GA_ACT_LRELU) || (act == GA_ACT_LRELU && !y)) return GA_ERR_ARG;
     if (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)y) & 15) return GA_ERR_ALIGN;
     const dim3 grid = cn_grid(dtype, B, HW, C, true);
-    const size_t lds = (size_t)2 * C * sizeof(float);
+    const size_t lds = (size_t)2 * C * sizeof(double);
     CN_DISPATCH(dtype,
                 (cnorm_bwd_stats_kernel<float><<<grid, 256, lds, s>>>((const float*)gy, (const float*)x, (const float*)y, (int)HW, C, groups, mean,
                                                                       rstd, act, gsums)),
@@ -277,7 +279,7 @@ int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, 
 }
 
 int ga_cnorm_bwd_apply(const void* gy, const void* x, const void* y, void* gx, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, const float* gamma, const float* gsums, int act, int frozen, hipStream_t s) {
+                       const float* rstd, const float* gamma, const double* gsums, int act, int frozen, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
     if (!gy || !x || !gx || !mean || !rstd || !gsums || (act != GA_ACT_NONE && act != GA_ACT_LRELU) || (act == GA_ACT_LRELU && !y))

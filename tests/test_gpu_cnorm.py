@@ -113,7 +113,7 @@ def test_refusals_fall_back_to_the_torch_module():
     assert not lib.ga_cnorm_supported(L.DT_F32, 4, 100, 2048, 1)      # 512 pieces per row: more than a block
     assert not lib.ga_cnorm_supported(L.DT_F32, 4, 100, 32, 2)        # groups is B or 1
     x = torch.zeros(4, 100, 4, device=DEV, dtype=torch.bfloat16)
-    s = torch.zeros(4, 4, 2, device=DEV)
+    s = torch.zeros(4, 4, 2, device=DEV, dtype=torch.float64)
     assert lib.ga_cnorm_stats(x.data_ptr(), L.DT_BF16, 4, 100, 4, 4, s.data_ptr(), L.stream()) != 0
     m = nn.BatchNorm2d(32, momentum=None).to(DEV)                     # cumulative average: torch's module keeps it
     assert not C2.norm2d_supported(m, torch.zeros(2, 32, 4, 4, device=DEV))
