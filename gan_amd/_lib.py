@@ -158,6 +158,7 @@ _SIGNATURES = {
     "ga_lstm_bwd": [C.POINTER(LstmBwdParams), _P],
     "ga_grad_sqnorm": [_P, _Z, _P, _P],
     "ga_adamw_fused": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _P],
+    "ga_adamw_fused_devstep": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _P, _F, _F, _P, _I, _P],
 }
 EXPORTED = sorted(list(_SIGNATURES) + ["ga_packed_elems", "ga_build_target", "ga_lstm_persist_workspace_bytes"])
 

@@ -1074,7 +1074,12 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 // g_out (optional) receives the clipped gradient so p.grad matches the reference after the step.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, size_t n, AdamWArgs a, const float* __restrict__ sqnorm,
-                                                     int write_clipped_grad) {
+                                                     int write_clipped_grad, const int* __restrict__ step_dev) {
+    if (step_dev) {  // the step number lives in device memory (a recorded HIP graph replays this launch with the same arguments)
+        const int step = step_dev[0];
+        a.bc1 = (float)(1.0 - pow((double)a.beta1, (double)step));
+        a.bc2 = (float)(1.0 - pow((double)a.beta2, (double)step));
+    }
     float coef = a.grad_scale;
     if (a.max_norm > 0.f && sqnorm) {
         const float total = sqrtf(sqnorm[0]) * a.grad_scale;
@@ -1521,7 +1526,22 @@ int ga_adamw_fused(float* p, float* g, float* m, float* v, size_t n, float lr, f
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2 = (float)(1.0 - pow((double)beta2, step));
     a.max_norm = max_norm; a.grad_scale = grad_scale;
-    adamw_kernel<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, s>>>(p, g, m, v, n, a, sqnorm, write_clipped_grad);
+    adamw_kernel<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, s>>>(p, g, m, v, n, a, sqnorm, write_clipped_grad, nullptr);
+    GA_CHECK_LAUNCH();
+    return GA_OK;
+}
+
+int ga_adamw_fused_devstep(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, const int* step_dev, float max_norm, float grad_scale, const float* sqnorm,
+                           int write_clipped_grad, hipStream_t s) {
+    if (!p || !g || !m || !v || !step_dev) return GA_ERR_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return GA_ERR_ALIGN;
+    if (n == 0) return GA_OK;
+    AdamWArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = a.bc2 = 1.f;  // from step_dev[0], in the kernel
+    a.max_norm = max_norm; a.grad_scale = grad_scale;
+    adamw_kernel<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, s>>>(p, g, m, v, n, a, sqnorm, write_clipped_grad, step_dev);
     GA_CHECK_LAUNCH();
     return GA_OK;
 }

@@ -53,6 +53,16 @@ class FusedAdamW:
         self.last_grad_norm: Optional[torch.Tensor] = None
         self.grad_scale = 1.0  # 1/world_size when flat_g holds a SUM over ranks
         self.sqnorm_hook = None  # called with the device scalar sum(g^2) between the norm kernel and the AdamW kernel
+        self.device_step: Optional[torch.Tensor] = None  # int32 [1] once use_device_step() was called (HIP-graph replays)
+
+    def use_device_step(self) -> None:
+        """Keep the step number in device memory as well: step() then increments it with a device op and the AdamW kernel reads it, so
+        an iteration recorded as a HIP graph applies the right bias correction on every replay.  The caller of a replay adds the replayed
+        steps to `step_count` (the host copy, which checkpoints save) itself."""
+        if self.device_step is None:
+            self.device_step = torch.full((1,), int(self.step_count), device=self.flat_p.device, dtype=torch.int32)
+        else:
+            self.device_step.fill_(int(self.step_count))
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
@@ -82,10 +92,17 @@ class FusedAdamW:
         L.check(lib.ga_grad_sqnorm(self.flat_g.data_ptr(), self.numel, self._sq.data_ptr(), L.stream()), "ga_grad_sqnorm")
         if self.sqnorm_hook is not None:
             self.sqnorm_hook(self._sq)  # data parallel: every rank clips by the same number (gan_amd/dp.py::DataParallel.sync_sqnorm)
-        L.check(lib.ga_adamw_fused(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                   self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                                   self.weight_decay, self.step_count, self.max_grad_norm, float(self.grad_scale),
-                                   self._sq.data_ptr(), 0, L.stream()), "ga_adamw_fused")
+        if self.device_step is not None:
+            self.device_step += 1
+            L.check(lib.ga_adamw_fused_devstep(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                                               self.weight_decay, self.device_step.data_ptr(), self.max_grad_norm, float(self.grad_scale),
+                                               self._sq.data_ptr(), 0, L.stream()), "ga_adamw_fused_devstep")
+        else:
+            L.check(lib.ga_adamw_fused(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                                       self.weight_decay, self.step_count, self.max_grad_norm, float(self.grad_scale),
+                                       self._sq.data_ptr(), 0, L.stream()), "ga_adamw_fused")
         self.last_grad_norm = self._sq.sqrt() * float(self.grad_scale)  # device tensor, no sync
 
     # torch.optim.AdamW-compatible checkpoint format (reference _save_stage_checkpoint, lab3_codec_train.py:225-243)
@@ -117,3 +134,5 @@ class FusedAdamW:
         if len(steps) > 1:
             raise ValueError("FusedAdamW keeps one step counter; the checkpoint has per-parameter steps that differ")
         self.step_count = steps.pop() if steps else 0
+        if self.device_step is not None:
+            self.device_step.fill_(int(self.step_count))

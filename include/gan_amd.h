@@ -469,6 +469,11 @@ int ga_grad_sqnorm(const float* g, size_t n, float* out, ga_stream_t stream);
 int ga_adamw_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float max_norm, float grad_scale, const float* sqnorm,
                    int write_clipped_grad, ga_stream_t stream);
+/* The same launch with the step number (>= 1) read from device memory by the kernel: for an iteration recorded as a HIP graph, whose
+ * replays repeat every launch with the recorded arguments (the caller increments *step_dev on the stream before this call). */
+int ga_adamw_fused_devstep(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, const int* step_dev, float max_norm, float grad_scale, const float* sqnorm,
+                           int write_clipped_grad, ga_stream_t stream);
 
 /* Two-layer LSTM + input skip of the frozen decoder (HF EncodecLSTM, modeling_encodec.py:236-249; reached through
  * lab3_codec_bridge.py:143).  All [B][T][*] buffers are channels-last.  Gate order i,f,g,o (torch nn.LSTM).
