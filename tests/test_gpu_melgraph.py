@@ -20,10 +20,10 @@ DEV = torch.device("cuda")
 KEYS = ("loss_g", "loss_d", "loss_adv", "loss_l1", "loss_mrstft")
 
 
-def _setup(period=1):
+def _setup(period=1, precision="fp32"):
     torch.manual_seed(21)
-    G = PM.ReconstructionDecoder(n_mels=32, n_frames=64, base_channels=64, precision="fp32").to(DEV).train()
-    D = PM.MelDiscriminator(base_channels=16, cond_dim=160, precision="fp32").to(DEV).train()
+    G = PM.ReconstructionDecoder(n_mels=32, n_frames=64, base_channels=64, precision=precision).to(DEV).train()
+    D = PM.MelDiscriminator(base_channels=16, cond_dim=160, precision=precision).to(DEV).train()
     cfg = PT.StageTrainConfig(stage_name="stage1", epochs=1, d_step_period=period, weights=PT.TrainWeights(content=0.0, style=0.0),
                               mrstft_resolutions=((32, 8, 32), (64, 16, 64)))
     return G, D, cfg
@@ -97,3 +97,21 @@ def test_train_stage1_with_the_graph_switch(tmp_path):
         assert float(ck["opt_g"]["state"][0]["step"]) == 6.0
     for k in ("loss_g", "loss_d", "loss_l1", "loss_mrstft"):
         assert hist["graph"][0][k] == pytest.approx(hist["eager"][0][k], rel=5e-3), k
+
+
+def test_bf16_replays_follow_the_eager_run_and_leave_usable_modules_behind():
+    """bf16 mode: the first replays against the eager run (later ones drift as any two bf16 runs do), and after the runner is gone the
+    modules still train eagerly (their gradients lived in the graph's memory pool)."""
+    G0, D0, cfg = _setup(1, "bf16")
+    batches = _batches(6)
+    _, _, _, _, le, _ = _run(G0, D0, cfg, batches, False)
+    Gg, Dg, ogg, odg, lg, runner = _run(G0, D0, cfg, batches, True)
+    for i in range(4):
+        for k, x, y in zip(KEYS, lg[i], le[i]):
+            assert x == pytest.approx(y, rel=5e-3 if i < 3 else 5e-2, abs=1e-5), (i, k, x, y)
+    del runner
+    import gc
+    gc.collect()
+    real, zc, cond = batches[0]
+    out = PT.mel_stage1_iteration(cfg, Gg, Dg, ogg, odg, real, zc, cond, 6)
+    assert all(bool(torch.isfinite(out[k])) for k in KEYS) and ogg.step_count == 7 and int(ogg.device_step) == 7
