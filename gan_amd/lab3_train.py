@@ -746,7 +746,7 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
                    loss_pfm, loss_contrastive, loss_infonce, loss_style_hinge, loss_lowmid, loss_flat, loss_timbre, loss_tilt, loss_zcr, loss_hf,
                    loss_highpass, loss_fm, loss_perc, loss_div, loss_mel_div, loss_prof)
             host = torch.tensor([float(content_w), float(cur_lr_g), 0.0, 1.0 if thaw_active else 0.0, float(cond_alpha)], dtype=torch.float64)
-            vals = torch.cat([torch.stack([v.detach().double().reshape(()) for v in row]), host.to(device)])
+            vals = torch.cat([torch.stack([v.detach().float().reshape(()) for v in row]).double(), host.to(device)])  # (one cast, not 27)
             vals[STAGE2_KEYS.index("style_conf")] = style_conf.detach().double()
             sums += vals
             nb += 1
