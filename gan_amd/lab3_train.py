@@ -320,6 +320,7 @@ class GraphedStage1:
                  warmup: int = 2):
         self.cfg, self.G, self.D, self.og, self.od, self.enc = stage_cfg, generator, discriminator, opt_g, opt_d, frozen_encoder
         self.warmup = int(warmup)
+        self.max_graphs = 4
         self.graphs: Dict = {}   # (do_d_step, batch shape) -> (graph, static inputs, static outputs)
         self.seen: Dict = {}
         from .lab3_bridge import FrozenLab1Encoder
@@ -342,8 +343,8 @@ class GraphedStage1:
         key = (do_d, tuple(real.shape), tuple(zc.shape), tuple(cond.shape), None if zs is None else tuple(zs.shape))
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
-        if n < self.warmup:
-            return self._eager(real, zc, cond, step_idx, zs)
+        if n < self.warmup or (key not in self.graphs and len(self.graphs) >= self.max_graphs):
+            return self._eager(real, zc, cond, step_idx, zs)  # (every recording keeps its activations: a loader of ever-changing shapes stays eager)
         from . import ops
         if key not in self.graphs:
             ins = [t.clone() if t is not None else None for t in (real, zc, cond, zs)]
