@@ -1,7 +1,5 @@
-"""(generated from tools/bench_melstage2.py by hand: the same run under the torch profiler)
-Mel-track stage-2 iteration time (train_stage2: the train-time StyleCritic, the frozen Lab1 encoder on the HIP kernels and the generator
-objective with the default weights plus the terms named on the command line) at the reference's default sizes, bf16.
-usage: bench_melstage2.py [batch] [all]      ("all": every one of the 23 generator terms weighted)"""
+"""Host-side view of the mel-track stage-2 iteration (bf16, reference sizes; the same set-up as tools/bench_melstage2.py): the second epoch of a
+train_stage2 run under the torch profiler -- operator counts, CPU time and device time per iteration.  usage: aten_ops_melstage2.py [batch] [all]"""
 import sys, tempfile, time
 from pathlib import Path
 import numpy as np
