@@ -10,6 +10,8 @@ nodes (ops.ConvTwice: the same three HIP kernels in permuted roles), BatchNorm's
 """
 from __future__ import annotations
 
+import contextlib
+
 import json
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -470,6 +472,14 @@ STAGE2_KEYS = ("loss_g", "loss_d", "loss_r1", "loss_sc", "loss_adv", "loss_l1", 
                "loss_target_profile", "content_weight", "lr_g", "style_conf", "style_thaw_active", "cond_alpha")  # history row, :690-723
 
 
+def _grad_if(weight) -> "contextlib.AbstractContextManager":
+    """A term whose weight is exactly zero still goes into the history row (the reference logs all of them), but its gradient would be
+    multiplied by zero: computed under no_grad, the value is the same, the generator's gradient is the same (the zero contributions are
+    simply not added) and its backward pass -- for `style_mid` a whole encoder pass -- is not run.  The reference's CLI defaults leave 13
+    of the 23 terms at zero (run_lab3.py:402-433)."""
+    return contextlib.nullcontext() if float(weight) != 0.0 else torch.no_grad()
+
+
 def _same_target_pair_hinge(feat: torch.Tensor, tgt_idx: torch.Tensor, margin: float, max_pairs: int) -> torch.Tensor:
     """`_diversity_loss` / `_mel_diversity_loss` (reference :580-605, :634-659): within every target genre, neighbours of a random
     permutation form pairs; mean over genres of mean relu(cos - margin), spending at most max_pairs pairs."""
@@ -675,46 +685,66 @@ def train_stage2(generator, discriminator, frozen_encoder, train_loader, cond_ba
             loss_adv = _gan_g_loss(stage_cfg.gan_loss, logit_fake_g, float(stage_cfg.g_real_label), float(stage_cfg.d_fake_label))
             with torch.no_grad():
                 _, d_real_feat = discriminator(real, cond_d, return_features=True)
-            loss_fm = F.l1_loss(d_fake_feat, d_real_feat)
+            # (every term is computed for the history row; the ones weighted zero without a backward pass: _grad_if)
+            with _grad_if(w.feature_match):
+                loss_fm = F.l1_loss(d_fake_feat, d_real_feat)
             fake_db = denormalize_log_mel(fake)
             enc_out = frozen_encoder.forward_log_mel_tensor(LL.lowpass_mel_db(fake_db, keep_bins=lp_bins))
-            enc_mid = frozen_encoder.forward_log_mel_tensor(LL.bandpass_mel_db(fake_db, low_bin=int(stage_cfg.style_mid_low_bin),
-                                                                              high_bin=int(stage_cfg.style_mid_high_bin)))
             loss_content = LL.cosine_distance(enc_out["z_content"], zc).mean()
             fake_zs = enc_out["z_style"]
             style_logits = style_critic(fake_zs)
             loss_style = F.cross_entropy(style_logits, tgt_idx, weight=class_w, label_smoothing=smoothing)
             conf = torch.softmax(style_logits, dim=1).gather(1, tgt_idx.unsqueeze(1)).squeeze(1)
             style_conf = conf.mean()
-            loss_style_mid = F.cross_entropy(style_critic(enc_mid["z_style"]), tgt_idx, weight=class_w, label_smoothing=smoothing)
-            loss_style_hinge = F.relu(float(stage_cfg.style_hinge_target_conf) - conf).mean()
-            proto_logits = F.normalize(fake_zs, dim=-1) @ protos.t() / float(stage_cfg.contrastive_temp)  # :572-578
-            loss_contrastive = F.cross_entropy(proto_logits, tgt_idx)
-            contrastive_conf = torch.softmax(proto_logits, dim=1).gather(1, tgt_idx.unsqueeze(1)).squeeze(1).mean()
+            with _grad_if(w.style_mid):
+                enc_mid = frozen_encoder.forward_log_mel_tensor(LL.bandpass_mel_db(fake_db, low_bin=int(stage_cfg.style_mid_low_bin),
+                                                                                  high_bin=int(stage_cfg.style_mid_high_bin)))
+                loss_style_mid = F.cross_entropy(style_critic(enc_mid["z_style"]), tgt_idx, weight=class_w, label_smoothing=smoothing)
+            with _grad_if(w.style_hinge):
+                loss_style_hinge = F.relu(float(stage_cfg.style_hinge_target_conf) - conf).mean()
+            with _grad_if(w.contrastive):
+                proto_logits = F.normalize(fake_zs, dim=-1) @ protos.t() / float(stage_cfg.contrastive_temp)  # :572-578
+                loss_contrastive = F.cross_entropy(proto_logits, tgt_idx)
+                contrastive_conf = torch.softmax(proto_logits, dim=1).gather(1, tgt_idx.unsqueeze(1)).squeeze(1).mean()
             with torch.no_grad():
                 enc_ref = frozen_encoder.forward_log_mel_tensor(real_db_lp[_target_reference_rows(gidx, tgt_idx)])
-            loss_pfm = (F.mse_loss(F.normalize(enc_out["shared_feat"], dim=-1), F.normalize(enc_ref["shared_feat"].detach(), dim=-1))
-                        + F.mse_loss(F.normalize(fake_zs, dim=-1), F.normalize(enc_ref["z_style"].detach(), dim=-1)))
-            loss_infonce = _within_genre_infonce(fake_zs, tgt_idx, float(stage_cfg.batch_infonce_temp))
+            with _grad_if(w.pfm_style):
+                loss_pfm = (F.mse_loss(F.normalize(enc_out["shared_feat"], dim=-1), F.normalize(enc_ref["shared_feat"].detach(), dim=-1))
+                            + F.mse_loss(F.normalize(fake_zs, dim=-1), F.normalize(enc_ref["z_style"].detach(), dim=-1)))
+            with _grad_if(w.batch_infonce_diversity):
+                loss_infonce = _within_genre_infonce(fake_zs, tgt_idx, float(stage_cfg.batch_infonce_temp))
             loss_l1 = F.l1_loss(fake, real)
-            loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions, precision=getattr(generator, "precision", "fp32"))
+            with _grad_if(float(w.continuity) if float(w.continuity) != 0.0 else float(w.mrstft)):
+                loss_continuity = multi_resolution_stft_loss(fake, real, resolutions=stage_cfg.mrstft_resolutions,
+                                                             precision=getattr(generator, "precision", "fp32"))
             loss_mrstft = loss_continuity
-            loss_lowmid = LL.frequency_weighted_l1_loss(fake, real, split_bin=int(stage_cfg.lowmid_split_bin),
-                                                        low_gain=float(stage_cfg.lowmid_gain), high_gain=float(stage_cfg.high_gain))
-            loss_highpass = LL.highpass_recon_l1_loss(fake, real, low_cut_bin=int(stage_cfg.highpass_cut_bin), gain=float(stage_cfg.highpass_gain))
-            loss_flat = LL.spectral_flatness_penalty_from_db(fake_db)
-            loss_timbre = LL.timbre_balance_penalty_from_db(fake_db)
-            loss_tilt = LL.spectral_tilt_penalty_from_db(fake_db, hf_to_lf_max_ratio=float(stage_cfg.spectral_tilt_max_ratio))
-            loss_zcr = LL.zcr_proxy_penalty_from_db(fake_db, target_max=float(stage_cfg.zcr_proxy_target_max))
-            loss_hf = LL.hf_excess_penalty_from_db(fake_db, real_db, top_frac=float(stage_cfg.hf_top_frac),
-                                                   max_ratio_multiplier=float(stage_cfg.hf_max_ratio_multiplier))
-            loss_perc = F.l1_loss(enc_out["shared_feat"], enc_real["shared_feat"].detach())
-            loss_div = _same_target_pair_hinge(d_fake_feat, tgt_idx, float(stage_cfg.diversity_margin), int(stage_cfg.diversity_max_pairs))
-            loss_mel_div = _same_target_pair_hinge(fake.flatten(1), tgt_idx, float(stage_cfg.mel_diversity_margin),
-                                                   int(stage_cfg.mel_diversity_max_pairs))
+            with _grad_if(w.lowmid_recon):
+                loss_lowmid = LL.frequency_weighted_l1_loss(fake, real, split_bin=int(stage_cfg.lowmid_split_bin),
+                                                            low_gain=float(stage_cfg.lowmid_gain), high_gain=float(stage_cfg.high_gain))
+            with _grad_if(w.highpass_anchor):
+                loss_highpass = LL.highpass_recon_l1_loss(fake, real, low_cut_bin=int(stage_cfg.highpass_cut_bin), gain=float(stage_cfg.highpass_gain))
+            with _grad_if(w.flatness):
+                loss_flat = LL.spectral_flatness_penalty_from_db(fake_db)
+            with _grad_if(w.timbre_balance):
+                loss_timbre = LL.timbre_balance_penalty_from_db(fake_db)
+            with _grad_if(w.spectral_tilt):
+                loss_tilt = LL.spectral_tilt_penalty_from_db(fake_db, hf_to_lf_max_ratio=float(stage_cfg.spectral_tilt_max_ratio))
+            with _grad_if(w.zcr_proxy):
+                loss_zcr = LL.zcr_proxy_penalty_from_db(fake_db, target_max=float(stage_cfg.zcr_proxy_target_max))
+            with _grad_if(w.hf_muzzle):
+                loss_hf = LL.hf_excess_penalty_from_db(fake_db, real_db, top_frac=float(stage_cfg.hf_top_frac),
+                                                       max_ratio_multiplier=float(stage_cfg.hf_max_ratio_multiplier))
+            with _grad_if(w.perceptual):
+                loss_perc = F.l1_loss(enc_out["shared_feat"], enc_real["shared_feat"].detach())
+            with _grad_if(w.diversity):
+                loss_div = _same_target_pair_hinge(d_fake_feat, tgt_idx, float(stage_cfg.diversity_margin), int(stage_cfg.diversity_max_pairs))
+            with _grad_if(w.mel_diversity):
+                loss_mel_div = _same_target_pair_hinge(fake.flatten(1), tgt_idx, float(stage_cfg.mel_diversity_margin),
+                                                       int(stage_cfg.mel_diversity_max_pairs))
             if target_profile_bank is not None:  # time-summed power per mel bin, as a distribution (:971-976)
-                prof = torch.pow(10.0, fake_db / 10.0).clamp_min(1e-10).sum(dim=2)
-                loss_prof = F.l1_loss(prof / (prof.sum(dim=1, keepdim=True) + 1e-8), target_profile_bank[tgt_idx])
+                with _grad_if(w.target_profile):
+                    prof = torch.pow(10.0, fake_db / 10.0).clamp_min(1e-10).sum(dim=2)
+                    loss_prof = F.l1_loss(prof / (prof.sum(dim=1, keepdim=True) + 1e-8), target_profile_bank[tgt_idx])
             else:
                 loss_prof = torch.zeros((), device=fake.device)
             if stage_cfg.adaptive_content_weight:  # :980-990

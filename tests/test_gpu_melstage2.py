@@ -224,3 +224,46 @@ def test_bf16_mode_r1_and_stage2_stay_close_to_fp32(tmp_path, monkeypatch):
         want = float(GOLD[f"stage2/all_terms/hist/1/{k}"])
         worst = max(worst, abs(hist[0][k] - want) / max(1.0, abs(want)))
     assert worst <= 3e-2, worst
+
+
+def test_zero_weighted_terms_without_a_backward_pass_change_nothing(tmp_path, monkeypatch):
+    """train_stage2 computes every term for the history row but skips the backward pass of those weighted exactly zero
+    (lab3_train._grad_if; the reference's CLI defaults leave 13 of 23 at zero).  Against the same run with every term differentiated,
+    as the reference does it: the history rows and the first AdamW step of every network are the same (a zero-weighted term contributes
+    0 * gradient, which is not added any more), to the run-to-run order of floating-point atomics."""
+    import contextlib
+    kw, _, _ = C.CASES["all_terms"]
+    kw = dict(kw, epochs=1)
+    weights = dict(C.ALL_WEIGHTS, style_mid=0.0, pfm_style=0.0, diversity=0.0, mel_diversity=0.0, batch_infonce_diversity=0.0, contrastive=0.0,
+                   style_hinge=0.0, feature_match=0.0, perceptual=0.0, lowmid_recon=0.0, spectral_tilt=0.0, zcr_proxy=0.0, hf_muzzle=0.0,
+                   highpass_anchor=0.0, timbre_balance=0.0, target_profile=0.0, mrstft=0.0)
+    runs = {}
+    for name in ("skipped", "differentiated"):
+        G = PM.ReconstructionDecoder(**C.G_KW)
+        G.load_state_dict(fill_state_dict(G.state_dict(), 21))
+        D = PM.MelDiscriminator(base_channels=16, cond_dim=C.COND_DIM + (C.ZC_DIM if kw.get("disc_use_content_cond") else 0))
+        D.load_state_dict(fill_state_dict(D.state_dict(), 22))
+        G, D = G.to(DEV), D.to(DEV)
+        cond_bank, proto, prof = C.stage2_banks()
+        cfg = PT.StageTrainConfig(weights=PT.TrainWeights(**weights), **dict(kw, max_batches_per_epoch=1))
+        with monkeypatch.context() as m:
+            m.setattr(PT, "StyleCritic", lambda **k: PM.StyleCritic(dropout=0.0, **k))
+            if name == "differentiated":
+                m.setattr(PT, "_grad_if", lambda w: contextlib.nullcontext())
+            torch.manual_seed(C.STAGE2_SEED)
+            hist = PT.train_stage2(G, D, C.ToyFrozenEncoder(DEV), C.loader_for("all_terms"), cond_bank, proto, None, prof, DEV, cfg,
+                                   tmp_path / f"{name}.pt", resume=False)
+        runs[name] = (hist, torch.load(tmp_path / f"{name}.pt", map_location="cpu", weights_only=True))
+    (ha, pa), (hb, pb) = runs["skipped"], runs["differentiated"]
+    for k, v in ha[0].items():
+        if k != "stage":
+            assert v == pytest.approx(hb[0][k], rel=1e-6, abs=1e-7), k
+    for group in ("generator", "discriminator", "style_critic"):
+        for k, v in pa[group].items():
+            if not v.dtype.is_floating_point:
+                continue
+            d = float((v - pb[group][k]).abs().max())
+            if k.endswith("bias"):  # a conv bias in front of a norm layer has a zero gradient in exact arithmetic: AdamW steps it by
+                assert d <= 2.5 * 2e-4, (group, k, d)  # +-lr on rounding noise, whose sign no two runs share
+            else:
+                assert d <= 1e-6 + 1e-5 * float(pb[group][k].abs().max()), (group, k, d)
