@@ -128,7 +128,7 @@ class ChannelNorm(torch.autograd.Function):
         lib, st = L.lib(), L.stream()
         if frozen is None:
             sums = torch.zeros((B, C, 2), device=x.device, dtype=torch.float64)
-            mean = torch.empty((groups, C), device=x.device, dtype=torch.float32)
+            mean = torch.empty((groups, C), device=x.device, dtype=torch.float64)
             rstd = torch.empty_like(mean)
             L.check(lib.ga_cnorm_stats(x.data_ptr(), L.dt(x), B, HW, C, groups, sums.data_ptr(), st), "ga_cnorm_stats")
             rm, rv, mom = running if running is not None else (None, None, 0.0)
@@ -193,7 +193,7 @@ def norm2d_nhwc(m: torch.nn.Module, x: torch.Tensor, post_act: int = L.ACT_NONE)
     if m.training:
         m.num_batches_tracked += 1
         return ChannelNorm.apply(x, gamma, beta, 1, m.eps, post_act, (m.running_mean, m.running_var, float(m.momentum)), None)
-    frozen = (m.running_mean.float().view(1, -1).contiguous(), torch.rsqrt(m.running_var.float() + m.eps).view(1, -1).contiguous())
+    frozen = (m.running_mean.double().view(1, -1).contiguous(), torch.rsqrt(m.running_var.double() + m.eps).view(1, -1).contiguous())
     return ChannelNorm.apply(x, gamma, beta, 1, m.eps, post_act, None, frozen)
 
 

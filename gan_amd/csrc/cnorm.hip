@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void cnorm_stats_kernel(const T* __restrict__ 
 // mean / rstd per (group, channel); BatchNorm's running statistics (momentum update, unbiased variance) when given
 template <typename T>
 __global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, int C, int groups, const double* __restrict__ sums, float eps,
-                                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                      double* __restrict__ mean, double* __restrict__ rstd, float* __restrict__ run_mean,
                                       float* __restrict__ run_var, float momentum) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= groups * C) return;
@@ -76,9 +76,10 @@ __global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, in
     const double m1 = t1 / n;  // (double from here on: a handful of operations per channel)
     double var = t2 / n - m1 * m1;
     var = var > 0.0 ? var : 0.0;
-    const float mu = (float)((double)p + m1);
-    mean[i] = mu;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    const double mud = (double)p + m1;
+    const float mu = (float)mud;
+    mean[i] = mud;
+    rstd[i] = 1.0 / sqrt(var + (double)eps);
     if (run_mean && groups == 1) {
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
@@ -87,17 +88,20 @@ __global__ void cnorm_finalize_kernel(const T* __restrict__ x, int B, int HW, in
 
 template <typename T>
 __global__ __launch_bounds__(256) void cnorm_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C, int groups,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const double* __restrict__ mean, const double* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
     CN_MAP();
     if (!active) return;
-    float sc[EV], sh[EV];
+    // y = ((x - mean) * rstd) * gamma + beta with the subtraction FIRST (x * sc + (beta - mean * sc) cancels two numbers of size
+    // |mean| / std and carries their rounding into y); the mean as hi + lo floats
+    float mu[EV], mlo[EV], sc[EV], sh[EV];
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
-        const float rs = rstd[(size_t)g * C + c0 + e], mu = mean[(size_t)g * C + c0 + e];
-        const float gm = gamma ? gamma[c0 + e] : 1.f, bt = beta ? beta[c0 + e] : 0.f;
-        sc[e] = rs * gm;
-        sh[e] = bt - mu * rs * gm;
+        const double rs = rstd[(size_t)g * C + c0 + e], md = mean[(size_t)g * C + c0 + e];
+        mu[e] = (float)md;
+        mlo[e] = (float)(md - (double)mu[e]);
+        sc[e] = (float)(rs * (gamma ? (double)gamma[c0 + e] : 1.0));
+        sh[e] = beta ? beta[c0 + e] : 0.f;
     }
     for (int r = blockIdx.x * rpp + rl; r < HW; r += gridDim.x * rpp) {
         const size_t o = item + (size_t)r * C + c0;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(const T* __restrict__ 
         CnPack<T> w;
 #pragma unroll
         for (int e = 0; e < EV; ++e) {
-            float t = fmaf((float)v.v[e], sc[e], sh[e]);
+            float t = fmaf(((float)v.v[e] - mu[e]) - mlo[e], sc[e], sh[e]);
             if (act == GA_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
             w.v[e] = (T)t;
         }
@@ -116,16 +120,20 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(const T* __restrict__ 
 // gsums[b][c] = (sum g, sum g * xhat) over item b, g = gy * act'(y)
 template <typename T>
 __global__ __launch_bounds__(256) void cnorm_bwd_stats_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y, int HW,
-                                                              int C, int groups, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, int act, double* __restrict__ gsums) {
+                                                              int C, int groups, const double* __restrict__ mean,
+                                                              const double* __restrict__ rstd, int act, double* __restrict__ gsums) {
     CN_MAP();
     extern __shared__ double acc[];
     for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.0;
     __syncthreads();
     if (active) {
-        float mu[EV], rs[EV], s1[EV], s2[EV];
+        float mu[EV], mlo[EV], rs[EV], s1[EV], s2[EV];  // mean as hi + lo floats: xhat = ((x - hi) - lo) * rstd keeps the mean's low bits
 #pragma unroll
-        for (int e = 0; e < EV; ++e) { mu[e] = mean[(size_t)g * C + c0 + e]; rs[e] = rstd[(size_t)g * C + c0 + e]; s1[e] = 0.f; s2[e] = 0.f; }
+        for (int e = 0; e < EV; ++e) {
+            const double md = mean[(size_t)g * C + c0 + e];
+            mu[e] = (float)md; mlo[e] = (float)(md - (double)mu[e]);
+            rs[e] = (float)rstd[(size_t)g * C + c0 + e]; s1[e] = 0.f; s2[e] = 0.f;
+        }
         const int step = gridDim.x * rpp;
         int r = blockIdx.x * rpp + rl;
         auto add = [&](const CnPack<T>& vg, const CnPack<T>& vx, const CnPack<T>& vy) __attribute__((always_inline)) {
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void cnorm_bwd_stats_kernel(const T* __restric
                 float gg = (float)vg.v[e];
                 if (act == GA_ACT_LRELU) gg *= (float)vy.v[e] > 0.f ? 1.f : 0.2f;
                 s1[e] += gg;
-                s2[e] = fmaf(gg, ((float)vx.v[e] - mu[e]) * rs[e], s2[e]);
+                s2[e] = fmaf(gg, (((float)vx.v[e] - mu[e]) - mlo[e]) * rs[e], s2[e]);
             }
         };
         const T* yy = act == GA_ACT_LRELU ? y : x;  // without an activation the third stream is not looked at
@@ -159,20 +167,23 @@ __global__ __launch_bounds__(256) void cnorm_bwd_stats_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void cnorm_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y,
                                                               T* __restrict__ gx, int B, int HW, int C, int groups,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const double* __restrict__ mean, const double* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const double* __restrict__ gsums, int act,
                                                               int frozen) {
     CN_MAP();
     if (!active) return;
     const double inv_n = frozen ? 0.0 : 1.0 / (groups == 1 ? (double)B * (double)HW : (double)HW);
-    float mu[EV], rs[EV], k[EV], a1[EV], a2[EV];
+    // The input gradient has to sum to zero over the normalised set (that is what makes the gradient of a bias in FRONT of the layer
+    // zero); rounding the mean or sum(g)/N to fp32 leaves a residual of the same sign on every element, N times over -- 1e-7 relative,
+    // but AdamW divides by |g| and steps such a bias by a full lr.  So: the mean and both sums stay double, per element in double.
+    double mu[EV], rs[EV], k[EV], a1[EV], a2[EV];
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
         mu[e] = mean[(size_t)g * C + c0 + e];
         rs[e] = rstd[(size_t)g * C + c0 + e];
-        k[e] = rs[e] * (gamma ? gamma[c0 + e] : 1.f);
-        a1[e] = (float)(gsums[2 * ((size_t)g * C + c0 + e)] * inv_n);
-        a2[e] = (float)(gsums[2 * ((size_t)g * C + c0 + e) + 1] * inv_n);
+        k[e] = rs[e] * (gamma ? (double)gamma[c0 + e] : 1.0);
+        a1[e] = gsums[2 * ((size_t)g * C + c0 + e)] * inv_n;
+        a2[e] = gsums[2 * ((size_t)g * C + c0 + e) + 1] * inv_n;
     }
     for (int r = blockIdx.x * rpp + rl; r < HW; r += gridDim.x * rpp) {
         const size_t o = item + (size_t)r * C + c0;
@@ -183,8 +194,8 @@ __global__ __launch_bounds__(256) void cnorm_bwd_apply_kernel(const T* __restric
         for (int e = 0; e < EV; ++e) {
             float gg = (float)vg.v[e];
             if (act == GA_ACT_LRELU) gg *= (float)vy.v[e] > 0.f ? 1.f : 0.2f;
-            const float xh = ((float)vx.v[e] - mu[e]) * rs[e];
-            w.v[e] = (T)(k[e] * (gg - a1[e] - xh * a2[e]));
+            const double xh = ((double)(float)vx.v[e] - mu[e]) * rs[e];
+            w.v[e] = (T)(float)(k[e] * ((double)gg - a1[e] - xh * a2[e]));
         }
         *(CnPack<T>*)(gx + o) = w;
     }
@@ -234,7 +245,7 @@ int ga_cnorm_stats(const void* x, int dtype, int B, long HW, int C, int groups, 
     return GA_OK;
 }
 
-int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const double* sums, float eps, float* mean, float* rstd,
+int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const double* sums, float eps, double* mean, double* rstd,
                       float* running_mean, float* running_var, float momentum, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
@@ -248,7 +259,7 @@ int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int group
     return GA_OK;
 }
 
-int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int groups, const float* mean, const float* rstd,
+int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int groups, const double* mean, const double* rstd,
                    const float* gamma, const float* beta, int act, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
@@ -261,8 +272,8 @@ int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int
     return GA_OK;
 }
 
-int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, int act, double* gsums, hipStream_t s) {
+int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, int B, long HW, int C, int groups, const double* mean,
+                       const double* rstd, int act, double* gsums, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
     if (!gy || !x || !mean || !rstd || !gsums || (act != GA_ACT_NONE && act != GA_ACT_LRELU) || (act == GA_ACT_LRELU && !y)) return GA_ERR_ARG;
@@ -278,8 +289,8 @@ int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, 
     return GA_OK;
 }
 
-int ga_cnorm_bwd_apply(const void* gy, const void* x, const void* y, void* gx, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, const float* gamma, const double* gsums, int act, int frozen, hipStream_t s) {
+int ga_cnorm_bwd_apply(const void* gy, const void* x, const void* y, void* gx, int dtype, int B, long HW, int C, int groups, const double* mean,
+                       const double* rstd, const float* gamma, const double* gsums, int act, int frozen, hipStream_t s) {
     const int rc = cn_check(dtype, B, HW, C, groups);
     if (rc) return rc;
     if (!gy || !x || !gx || !mean || !rstd || !gsums || (act != GA_ACT_NONE && act != GA_ACT_LRELU) || (act == GA_ACT_LRELU && !y))

@@ -385,7 +385,7 @@ int ga_rowgather_bwd(const void* gy, void* gx, int dtype, int B, int H, int W, i
  * (lab 3/src/lab3_models.py:80-83 `norm2d`, :85-105 up-blocks, :159-165), on channels-last memory x, y: [B][HW][C], C a multiple of the
  * 16-byte piece and at most 256 pieces (ga_cnorm_supported says).  groups = B: statistics per item and channel (instance norm); groups = 1:
  * per channel over B*HW rows (batch norm).  Forward: ga_cnorm_stats adds (sum(x - p), sum((x - p)^2)) about the pivot p = the group's first
- * row into the per-item sums[B][C][2] (DOUBLE: the atomics' order then does not show in fp32; caller zeroes); ga_cnorm_finalize adds the items of a group and turns them into mean / rstd [groups][C] (biased variance, eps inside the
+ * row into the per-item sums[B][C][2] (DOUBLE: the atomics' order then does not show in fp32; caller zeroes); ga_cnorm_finalize adds the items of a group and turns them into mean / rstd [groups][C] (DOUBLE as well: the input gradient must sum to zero, and fp32 statistics leave a same-signed residual) (biased variance, eps inside the
  * root) and, when running_mean / running_var are given (groups = 1), applies torch's momentum update with the unbiased variance;
  * ga_cnorm_apply writes y = act((x - mean) * rstd * gamma + beta), act GA_ACT_NONE or GA_ACT_LRELU, gamma / beta may be NULL (1 / 0).
  * Backward: ga_cnorm_bwd_stats adds (sum g, sum g * xhat), g = gy * act'(y), into the per-item gsums[B][C][2] (caller zeroes; summed over B
@@ -393,14 +393,14 @@ int ga_rowgather_bwd(const void* gy, void* gx, int dtype, int B, int H, int W, i
  * gamma * rstd * g when `frozen` (eval-mode batch norm: mean / rstd from the running statistics). */
 int ga_cnorm_supported(int dtype, int B, long HW, int C, int groups);
 int ga_cnorm_stats(const void* x, int dtype, int B, long HW, int C, int groups, double* sums, ga_stream_t stream);
-int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const double* sums, float eps, float* mean, float* rstd,
+int ga_cnorm_finalize(const void* x, int dtype, int B, long HW, int C, int groups, const double* sums, float eps, double* mean, double* rstd,
                       float* running_mean, float* running_var, float momentum, ga_stream_t stream);
-int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int groups, const float* mean, const float* rstd,
+int ga_cnorm_apply(const void* x, void* y, int dtype, int B, long HW, int C, int groups, const double* mean, const double* rstd,
                    const float* gamma, const float* beta, int act, ga_stream_t stream);
-int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, int act, double* gsums, ga_stream_t stream);
-int ga_cnorm_bwd_apply(const void* gy, const void* x, const void* y, void* gx, int dtype, int B, long HW, int C, int groups, const float* mean,
-                       const float* rstd, const float* gamma, const double* gsums, int act, int frozen, ga_stream_t stream);
+int ga_cnorm_bwd_stats(const void* gy, const void* x, const void* y, int dtype, int B, long HW, int C, int groups, const double* mean,
+                       const double* rstd, int act, double* gsums, ga_stream_t stream);
+int ga_cnorm_bwd_apply(const void* gy, const void* x, const void* y, void* gx, int dtype, int B, long HW, int C, int groups, const double* mean,
+                       const double* rstd, const float* gamma, const double* gsums, int act, int frozen, ga_stream_t stream);
 /* out[m] += sum_rows g[row][m]: bias gradient of conv1d (atomics; caller zeroes) */
 int ga_colsum(const void* g, int dtype, size_t rows, int M, float* out, ga_stream_t stream);
 

